@@ -1,0 +1,305 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4), exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Replaces, on the reference's path, every cuDNN/cuBLAS contraction reached through
+// detectron2's backbone / FPN / RPN head / box head / mask head and the association FC
+// (/root/reference/dcnn/networks/track_rcnn.py:42-51, dcnn/networks/association_head.py:23).
+//
+// GEMM view:  D[m][n] = sum_k A[m][k] * Wt[n][k]
+//   m = (b, oy, ox) output pixel, n = output channel, k = (r, q) with q running over the
+//   contiguous NHWC run of KW pixels x Cin channels of filter row r (so one k-step of 32 floats
+//   is one 128-byte contiguous read per output pixel; out-of-image pixels are zero-filled).
+// Block = 256 threads = 4 waves (one per SIMD); wave tile = TM x TN MFMA tiles of 32x32.
+// LDS: A and B k-slices [rows][32 f32] double-buffered, 16-byte slots XOR-swizzled with
+// (row>>1)&7 so both the ds_write_b128 staging and the ds_read_b128 fragment reads are
+// bank-conflict-free (MI355X_MICROARCH.md, LDS table: b128 reads are served per 16-lane group
+// over 64 banks).  One ds_read_b128 feeds FOUR MFMA k-steps: lane half h takes k = 8c+4h+j for
+// step j (the k order inside a chunk is a free choice as long as A and B agree).
+// Global->LDS staging goes through registers (issue loads for step s+1, run the MFMAs of step
+// s, then write LDS): an f32 MFMA k-step is 4096 cycles/wave at 128x128, so the loads are
+// always back before they are needed; one barrier per k-step.
+#include "apse_common.h"
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int AP = BM / 32;   // staging passes (32 rows x 8 slots of 16 B per pass)
+    constexpr int BP = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);   // [2][BM*32]
+    float* Bs = As + 2 * BM * 32;                 // [2][BN*32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    int M = p.M;
+    if (p.m_count) {
+        int lim = (*p.m_count) * p.m_per_item;
+        M = lim < M ? lim : M;
+    }
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    // XCD-aware remap (blocks are dealt round-robin over 8 XCDs): give each XCD a contiguous
+    // range of tiles so neighbours that share an activation tile share an L2.  Bijective form.
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (m0 >= M) return;
+
+    const int z = blockIdx.y;
+    const int per = (p.steps_total + p.splitk - 1) / p.splitk;
+    const int s_begin = z * per;
+    const int s_end = (s_begin + per < p.steps_total) ? s_begin + per : p.steps_total;
+    const int steps_per_row = p.KWCp >> 5;
+
+    // per-thread staging rows
+    const int srow = tid >> 3, slot = tid & 7;
+    int a_iy0[AP], a_ix0[AP], a_pix[AP];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + srow + 32 * i;
+        if (m < M) {
+            const int b = m / ohw;
+            const int rem = m - b * ohw;
+            const int oy = rem / p.OW;
+            const int ox = rem - oy * p.OW;
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
+            a_pix[i] = b * p.H * p.W;
+        } else {
+            a_iy0[i] = -(1 << 28);   // never valid
+            a_ix0[i] = 0;
+            a_pix[i] = 0;
+        }
+    }
+    const size_t w_row = (size_t)p.KH * p.KWCp;
+
+    f32x4 ra[AP], rb[BP];
+    auto load_step = [&](int s) {
+        const int r = s / steps_per_row;
+        const int q = ((s - r * steps_per_row) << 5) + (slot << 2);
+        const int dpx = q >> p.cin_log2;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int iy = a_iy0[i] + r;
+            const int px = a_ix0[i] + dpx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)px < (unsigned)p.W) {
+                const int off = ((a_pix[i] + iy * p.W + a_ix0[i]) << p.cin_log2) + q;
+                v = *reinterpret_cast<const f32x4*>(p.x + off);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const int n = n0 + srow + 32 * i;
+            rb[i] = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * w_row + (size_t)r * p.KWCp + q);
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int row = srow + 32 * i;
+            const int ps = slot ^ ((row >> 1) & 7);
+            *reinterpret_cast<f32x4*>(As + buf * BM * 32 + row * 32 + ps * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const int row = srow + 32 * i;
+            const int ps = slot ^ ((row >> 1) & 7);
+            *reinterpret_cast<f32x4*>(Bs + buf * BN * 32 + row * 32 + ps * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    if (s_begin < s_end) {
+        load_step(s_begin);
+        store_step(0);
+        __syncthreads();
+        for (int s = s_begin; s < s_end; ++s) {
+            const int buf = (s - s_begin) & 1;
+            if (s + 1 < s_end) load_step(s + 1);
+            const float* Ab = As + buf * BM * 32;
+            const float* Bb = Bs + buf * BN * 32;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 af[TM], bf[TN];
+                const int ls = 2 * c + fh;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wm * TM + i) * 32 + fr;
+                    af[i] = *reinterpret_cast<const f32x4*>(Ab + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = (wn * TN + j) * 32 + fr;
+                    bf[j] = *reinterpret_cast<const f32x4*>(Bb + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][k], bf[j][k], acc[i][j], 0, 0, 0);
+            }
+            if (s + 1 < s_end) store_step(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // C/D map of the 32x32 MFMA: col = lane&31 (n), row = (v&3) + 8*(v>>2) + 4*(lane>>5) (m).
+    const bool direct = (p.splitk == 1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + fr;
+            if (n >= p.Cout) continue;
+            float bias = 0.f;
+            int co = n, g = 0;
+            if (direct) {
+                if (p.out_mode == 1) { g = n / p.cdec; co = n - g * p.cdec; }
+                if (p.bias) bias = p.bias[co];
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * fh;
+                if (m >= M) continue;
+                float val = acc[i][j][v];
+                if (!direct) {
+                    p.ws[((size_t)z * p.M + m) * p.Cout + n] = val;
+                    continue;
+                }
+                val += bias;
+                if (p.out_mode == 0) {
+                    if (p.res_mode == 1) {
+                        val += p.res[(size_t)m * p.Cout + n];
+                    } else if (p.res_mode == 2) {
+                        const int b = m / ohw;
+                        const int rem = m - b * ohw;
+                        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                        const int hw2 = (p.OH >> 1) * (p.OW >> 1);
+                        val += p.res[((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n];
+                    }
+                    if (p.relu) val = val > 0.f ? val : 0.f;
+                    p.y[(size_t)m * p.y_ld + p.y_coff + n] = val;
+                } else {
+                    const int b = m / ohw;
+                    const int rem = m - b * ohw;
+                    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                    const int dy = g >> 1, dx = g & 1;
+                    if (p.relu) val = val > 0.f ? val : 0.f;
+                    p.y[(((size_t)b * 2 * p.OH + 2 * oy + dy) * (2 * p.OW) + 2 * ox + dx) * p.cdec + co] = val;
+                }
+            }
+        }
+    }
+}
+
+// Split-K second pass: fixed-order sum of the partial slabs (bitwise reproducible) + epilogue.
+__global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvParams p) {
+    int M = p.M;
+    if (p.m_count) {
+        int lim = (*p.m_count) * p.m_per_item;
+        M = lim < M ? lim : M;
+    }
+    const size_t total = (size_t)M * p.Cout;
+    const int ohw = p.OH * p.OW;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(e / p.Cout);
+        const int n = (int)(e - (size_t)m * p.Cout);
+        float val = 0.f;
+        for (int z = 0; z < p.splitk; ++z) val += p.ws[((size_t)z * p.M + m) * p.Cout + n];
+        int co = n, g = 0;
+        if (p.out_mode == 1) { g = n / p.cdec; co = n - g * p.cdec; }
+        if (p.bias) val += p.bias[co];
+        if (p.out_mode == 0) {
+            if (p.res_mode == 1) {
+                val += p.res[(size_t)m * p.Cout + n];
+            } else if (p.res_mode == 2) {
+                const int b = m / ohw;
+                const int rem = m - b * ohw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                const int hw2 = (p.OH >> 1) * (p.OW >> 1);
+                val += p.res[((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n];
+            }
+            if (p.relu) val = val > 0.f ? val : 0.f;
+            p.y[(size_t)m * p.y_ld + p.y_coff + n] = val;
+        } else {
+            const int b = m / ohw;
+            const int rem = m - b * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            const int dy = g >> 1, dx = g & 1;
+            if (p.relu) val = val > 0.f ? val : 0.f;
+            p.y[(((size_t)b * 2 * p.OH + 2 * oy + dy) * (2 * p.OW) + 2 * ox + dx) * p.cdec + co] = val;
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_cfg(const ConvParams& p, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+    const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN>), dim3(tiles, p.splitk), dim3(256), lds, s, p);
+    if (p.splitk > 1) {
+        const size_t total = (size_t)p.M * p.Cout;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv_splitk_reduce, dim3(blocks), dim3(256), 0, s, p);
+    }
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+
+int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s) {
+    if (p.M <= 0 || p.Cout <= 0 || p.steps_total <= 0) return APSE_E_INVALID;
+    switch (cfg) {
+        case 0: return launch_cfg<2, 2, 2, 2>(p, s);
+        case 1: return launch_cfg<2, 2, 1, 1>(p, s);
+        case 2: return launch_cfg<4, 1, 1, 1>(p, s);
+        case 3: return launch_cfg<4, 1, 1, 2>(p, s);
+        default: return APSE_E_INVALID;
+    }
+}
+
+// Tile/split heuristic: fill >= ~1 wave of the 256 CUs; prefer the largest tile that does.
+int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk) {
+    *splitk = 1;
+    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
+    if (Cout <= 32) return 2;
+    if (Cout <= 64) return tiles(128, 64) >= 192 ? 3 : 1;
+    if (tiles(128, 128) >= 224) return 0;
+    int t = tiles(64, 64);
+    if (t < 128 && steps >= 16) {
+        int sk = (256 + t - 1) / t;
+        if (sk > steps / 4) sk = steps / 4;
+        if (sk > 64) sk = 64;
+        if (sk < 1) sk = 1;
+        *splitk = sk;
+    }
+    return 1;
+}

@@ -1,0 +1,179 @@
+// HBM-bound elementwise / resampling kernels of the dcnn hot path (gfx950).
+//  * PIL-style antialiased bilinear resize (two integer passes, bit-exact with Pillow's
+//    Resample.c 8bpc path) fused with mean subtraction and /32 zero padding:
+//    replaces ResizeShortestEdge.apply_image + GeneralizedRCNN.preprocess_image
+//    (/root/reference/dcnn/engines/track_predictor.py:48-49, dcnn/networks/track_rcnn.py:35).
+//  * stem max-pool 3x3/2 and FPN p6 subsample (detectron2 ResNet stem / LastLevelMaxPool,
+//    reached from track_rcnn.py:42).
+#include "apse_common.h"
+
+#define PIL_PRECISION_BITS 22
+
+__device__ __forceinline__ int clip8(int v) {
+    v >>= PIL_PRECISION_BITS;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// Horizontal pass: one block per input row.  The row (W*3 bytes, BGR interleaved) is staged in
+// LDS with coalesced 4-byte loads; each thread then produces output samples (ox, c).
+// bounds: [OW][2] = (xmin, count); coef: [OW][ksize] int32 (Pillow normalize_coeffs_8bpc).
+__global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp,
+                                                    const int* __restrict__ bounds, const int* __restrict__ coef,
+                                                    int H, int W, int OW, int ksize, size_t src_img_stride,
+                                                    size_t tmp_img_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t* row = reinterpret_cast<uint8_t*>(smem);
+    const int y = blockIdx.x, b = blockIdx.y;
+    const uint8_t* srow = src + (size_t)b * src_img_stride + (size_t)y * W * 3;
+    const int nbytes = W * 3;
+    // W*3 is a multiple of 4 for every supported width (W % 4 == 0); rows start 4-byte aligned.
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(srow);
+    uint32_t* r4 = reinterpret_cast<uint32_t*>(row);
+    for (int i = threadIdx.x; i < (nbytes >> 2); i += blockDim.x) r4[i] = s4[i];
+    __syncthreads();
+    uint8_t* orow = tmp + (size_t)b * tmp_img_stride + (size_t)y * OW * 3;
+    for (int o = threadIdx.x; o < OW * 3; o += blockDim.x) {
+        const int ox = o / 3, c = o - ox * 3;
+        const int xmin = bounds[2 * ox], cnt = bounds[2 * ox + 1];
+        const int* k = coef + ox * ksize;
+        int ss = 1 << (PIL_PRECISION_BITS - 1);
+        for (int j = 0; j < cnt; ++j) ss += (int)row[(xmin + j) * 3 + c] * k[j];
+        orow[o] = (uint8_t)clip8(ss);
+    }
+}
+
+// Vertical pass + normalise + pad: out is NHWC4 f32 [B][PH][PW][4]; only the OHxOW interior is
+// written (the pad area and channel 3 are zeroed once at allocation and never touched).
+__global__ __launch_bounds__(256) void pil_resize_v_norm(const uint8_t* __restrict__ tmp, float* __restrict__ out,
+                                                         const int* __restrict__ bounds, const int* __restrict__ coef,
+                                                         int OH, int OW, int ksize, int PH, int PW,
+                                                         float m0, float m1, float m2, size_t tmp_img_stride,
+                                                         uint8_t* __restrict__ resized_u8) {
+    const int oy = blockIdx.y, b = blockIdx.z;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= OW * 3) return;
+    const int ymin = bounds[2 * oy], cnt = bounds[2 * oy + 1];
+    const int* k = coef + oy * ksize;
+    const uint8_t* t = tmp + (size_t)b * tmp_img_stride + (size_t)ymin * OW * 3 + o;
+    int ss = 1 << (PIL_PRECISION_BITS - 1);
+    for (int j = 0; j < cnt; ++j) ss += (int)t[(size_t)j * OW * 3] * k[j];
+    const int v = clip8(ss);
+    const int ox = o / 3, c = o - ox * 3;
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+    out[(((size_t)b * PH + oy) * PW + ox) * 4 + c] = (float)v - mean;
+    if (resized_u8) resized_u8[((size_t)b * OH + oy) * OW * 3 + o] = (uint8_t)v;
+}
+
+// f32 CHW (the reference's model input, track_predictor.py:49) -> normalised padded NHWC4.
+__global__ __launch_bounds__(256) void chw_to_nhwc4_norm(const float* __restrict__ img, float* __restrict__ out, int OH,
+                                                         int OW, int PH, int PW, float m0, float m1, float m2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= OH * OW) return;
+    const int oy = i / OW, ox = i - oy * OW;
+    const float* p = img + (size_t)b * 3 * OH * OW;
+    f32x4 v = {p[i] - m0, p[(size_t)OH * OW + i] - m1, p[(size_t)2 * OH * OW + i] - m2, 0.f};
+    *reinterpret_cast<f32x4*>(out + (((size_t)b * PH + oy) * PW + ox) * 4) = v;
+}
+
+// max_pool2d(k=3, s=2, p=1) on NHWC f32, C % 4 == 0.  One thread per (pixel, 4 channels).
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* __restrict__ x, float* __restrict__ y, int B, int H,
+                                                         int W, int C, int OH, int OW) {
+    const int c4 = C >> 2;
+    const size_t total = (size_t)B * OH * OW * c4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % c4);
+        size_t pix = e / c4;
+        const int ox = (int)(pix % OW);
+        pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int b = (int)(pix / OH);
+        f32x4 m = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + c * 4);
+                m[0] = v[0] > m[0] ? v[0] : m[0];
+                m[1] = v[1] > m[1] ? v[1] : m[1];
+                m[2] = v[2] > m[2] ? v[2] : m[2];
+                m[3] = v[3] > m[3] ? v[3] : m[3];
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + (((size_t)b * OH + oy) * OW + ox) * C + c * 4) = m;
+    }
+}
+
+// max_pool2d(k=1, s=2): p6 = p5[:, ::2, ::2]
+__global__ __launch_bounds__(256) void subsample2_nhwc(const float* __restrict__ x, float* __restrict__ y, int B, int H,
+                                                       int W, int C, int OH, int OW) {
+    const int c4 = C >> 2;
+    const size_t total = (size_t)B * OH * OW * c4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % c4);
+        size_t pix = e / c4;
+        const int ox = (int)(pix % OW);
+        pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int b = (int)(pix / OH);
+        *reinterpret_cast<f32x4*>(y + (((size_t)b * OH + oy) * OW + ox) * C + c * 4) =
+            *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c * 4);
+    }
+}
+
+// NHWC -> NCHW copy (exposes p2..p6 in the layout the reference API returns).
+__global__ __launch_bounds__(256) void nhwc_to_nchw(const float* __restrict__ x, float* __restrict__ y, int B, int HW, int C) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        tile[i][tx] = (p < HW && c < C) ? x[((size_t)b * HW + p) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        if (p < HW && c < C) y[((size_t)b * C + c) * HW + p] = tile[tx][i];
+    }
+}
+
+extern "C" {
+int apse_k_pil_resize(const uint8_t* src, uint8_t* tmp, float* out, uint8_t* resized_u8, const int* hb, const int* hc,
+                      int hk, const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,
+                      const float* mean, hipStream_t s) {
+    if ((W & 3) != 0 || (size_t)W * 3 > 150000) return APSE_E_INVALID;
+    hipLaunchKernelGGL(pil_resize_h, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
+                       (size_t)H * W * 3, (size_t)H * OW * 3);
+    hipLaunchKernelGGL(pil_resize_v_norm, dim3((OW * 3 + 255) / 256, OH, B), dim3(256), 0, s, tmp, out, vb, vc, OH, OW, vk,
+                       PH, PW, mean[0], mean[1], mean[2], (size_t)H * OW * 3, resized_u8);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_chw_norm(const float* img, float* out, int B, int OH, int OW, int PH, int PW, const float* mean, hipStream_t s) {
+    hipLaunchKernelGGL(chw_to_nhwc4_norm, dim3((OH * OW + 255) / 256, B), dim3(256), 0, s, img, out, OH, OW, PH, PW, mean[0],
+                       mean[1], mean[2]);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, hipStream_t s) {
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    size_t total = (size_t)B * OH * OW * (C / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(maxpool3x3s2_nhwc, dim3(blocks), dim3(256), 0, s, x, y, B, H, W, C, OH, OW);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_subsample2(const float* x, float* y, int B, int H, int W, int C, hipStream_t s) {
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    size_t total = (size_t)B * OH * OW * (C / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(subsample2_nhwc, dim3(blocks), dim3(256), 0, s, x, y, B, H, W, C, OH, OW);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_nhwc_to_nchw(const float* x, float* y, int B, int HW, int C, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_nchw, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, x, y, B, HW, C);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+}

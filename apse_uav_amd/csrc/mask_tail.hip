@@ -1,0 +1,271 @@
+// Mask tail (gfx950): detector_postprocess + paste_masks_in_image + the reference's mask geometry,
+// without materialising N x 2160 x 3840 masks.
+//
+//   det_postprocess : Boxes.scale / clip / nonempty + the integer paste window
+//                     (detectron2 detector_postprocess, reached from dcnn/networks/track_rcnn.py:57)
+//   paste_masks     : sigmoid -> bilinear grid_sample(align_corners=False, zero pad) -> >= 0.5, written as
+//                     bit-packed rows of the *frame* (one 64-bit word = 64 pixels), only inside the window;
+//                     integer centroid sums accumulated on the fly
+//                     (dcnn/utils/mask_utils.py:27-38 get_mask_centroid, 1-based coordinates)
+//   closest_points  : first row-major mask pixel minimising the f32 squared distance to a target point
+//                     (dcnn/utils/mask_utils.py:6-23 compute_closest_point); targets = every detection's
+//                     centroid in the same image, so the host pick (which needs track ids) happens later.
+// f32 arithmetic is compiled with -ffp-contract=off (products and sums rounded like the CPU path).
+#include "apse_common.h"
+
+struct PasteParams {
+    const float* boxes;      // packed [n][4], resized-image coordinates
+    const int* cls;          // packed [n]
+    const int* total;        // device count of packed detections
+    const float* logits;     // [n][M][M][ldc] mask head output (NHWC), class channel = cls[n]
+    int M, ldc;
+    float sx, sy;            // output/resized scale factors (f32 of the Python doubles)
+    int out_h, out_w;
+    int words_per_row;       // ceil(out_w / 64)
+    float thresh;
+    float* boxes_out;        // [n][4] scaled + clipped boxes
+    int* valid;              // [n] nonempty after scaling
+    int* rect;               // [n][4] x0, y0, x1, y1 paste window
+    uint64_t* bits;          // [n][out_h][words_per_row]
+    unsigned long long* sums;   // [n][3] mass, sum(x+1), sum(y+1)   (zeroed before launch)
+};
+
+__global__ void det_postprocess(const PasteParams p, int n_max) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_max || i >= *p.total) return;
+    float x0 = p.boxes[i * 4 + 0] * p.sx, y0 = p.boxes[i * 4 + 1] * p.sy;
+    float x1 = p.boxes[i * 4 + 2] * p.sx, y1 = p.boxes[i * 4 + 3] * p.sy;
+    const float w = (float)p.out_w, h = (float)p.out_h;
+    x0 = fminf(fmaxf(x0, 0.f), w); y0 = fminf(fmaxf(y0, 0.f), h);
+    x1 = fminf(fmaxf(x1, 0.f), w); y1 = fminf(fmaxf(y1, 0.f), h);
+    p.boxes_out[i * 4 + 0] = x0; p.boxes_out[i * 4 + 1] = y0; p.boxes_out[i * 4 + 2] = x1; p.boxes_out[i * 4 + 3] = y1;
+    const int ok = ((x1 - x0) > 0.f) && ((y1 - y0) > 0.f);
+    p.valid[i] = ok;
+    int rx0 = (int)fmaxf(floorf(x0) - 1.f, 0.f), ry0 = (int)fmaxf(floorf(y0) - 1.f, 0.f);
+    int rx1 = (int)fminf(ceilf(x1) + 1.f, w), ry1 = (int)fminf(ceilf(y1) + 1.f, h);
+    if (!ok) { rx1 = rx0; ry1 = ry0; }
+    p.rect[i * 4 + 0] = rx0; p.rect[i * 4 + 1] = ry0; p.rect[i * 4 + 2] = rx1; p.rect[i * 4 + 3] = ry1;
+}
+
+#define PASTE_ROWSPLIT 16
+// grid (n_max, PASTE_ROWSPLIT), 256 threads = 4 waves; wave w of block c handles window rows
+// y0 + (c*4 + w) + k * 4*PASTE_ROWSPLIT.  A wave covers 64 pixels per step; ballot -> one word.
+__global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_max) {
+    __shared__ float prob[32 * 32];
+    __shared__ unsigned long long red[4][3];
+    const int i = blockIdx.x;
+    if (i >= n_max || i >= *p.total) return;
+    if (!p.valid[i]) return;
+    const int M = p.M;
+    const int c = p.cls[i];
+    const float* lg = p.logits + (size_t)i * M * M * p.ldc + c;
+    for (int t = threadIdx.x; t < M * M; t += blockDim.x) prob[t] = 1.0f / (1.0f + expf(-lg[(size_t)t * p.ldc]));
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rx0 = p.rect[i * 4 + 0], ry0 = p.rect[i * 4 + 1], rx1 = p.rect[i * 4 + 2], ry1 = p.rect[i * 4 + 3];
+    const float bx0 = p.boxes_out[i * 4 + 0], by0 = p.boxes_out[i * 4 + 1];
+    const float bx1 = p.boxes_out[i * 4 + 2], by1 = p.boxes_out[i * 4 + 3];
+    const float bw = bx1 - bx0, bh = by1 - by0;
+    const float Mf = (float)M;
+    uint64_t* bits = p.bits + (size_t)i * p.out_h * p.words_per_row;
+    unsigned long long mass = 0, sx = 0, sy = 0;
+    const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
+    for (int y = ry0 + blockIdx.y * 4 + wave; y < ry1; y += 4 * PASTE_ROWSPLIT) {
+        // normalised y, grid_sample unnormalise (align_corners=False)
+        const float gy = ((float)y + 0.5f - by0) / bh * 2.0f - 1.0f;
+        const float iy = ((gy + 1.0f) * Mf - 1.0f) / 2.0f;
+        const float fy = floorf(iy);
+        const int iy0 = (int)fy, iy1 = iy0 + 1;
+        const float wy1 = iy - fy, wy0 = 1.0f - wy1;   // torch CPU grid_sample: n = y - floor(y), s = 1 - n
+        const bool y0in = (unsigned)iy0 < (unsigned)M, y1in = (unsigned)iy1 < (unsigned)M;
+        for (int w = w0; w < w1; ++w) {
+            const int x = (w << 6) + lane;
+            bool on = false;
+            if (x >= rx0 && x < rx1) {
+                const float gx = ((float)x + 0.5f - bx0) / bw * 2.0f - 1.0f;
+                const float ix = ((gx + 1.0f) * Mf - 1.0f) / 2.0f;
+                const float fx = floorf(ix);
+                const int ix0 = (int)fx, ix1 = ix0 + 1;
+                const float wx1 = ix - fx, wx0 = 1.0f - wx1;
+                const bool x0in = (unsigned)ix0 < (unsigned)M, x1in = (unsigned)ix1 < (unsigned)M;
+                float v = 0.f;
+                if (y0in && x0in) v += prob[iy0 * M + ix0] * (wy0 * wx0);
+                if (y0in && x1in) v += prob[iy0 * M + ix1] * (wy0 * wx1);
+                if (y1in && x0in) v += prob[iy1 * M + ix0] * (wy1 * wx0);
+                if (y1in && x1in) v += prob[iy1 * M + ix1] * (wy1 * wx1);
+                on = v >= p.thresh;
+            }
+            const uint64_t word = __ballot(on);
+            if (lane == 0) bits[(size_t)y * p.words_per_row + w] = word;
+            if (on) { mass += 1; sx += (unsigned long long)(x + 1); sy += (unsigned long long)(y + 1); }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mass += __shfl_xor(mass, o); sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o);
+    }
+    if (lane == 0) { red[wave][0] = mass; red[wave][1] = sx; red[wave][2] = sy; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const unsigned long long t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (t) atomicAdd(p.sums + (size_t)i * 3 + threadIdx.x, t);
+    }
+}
+
+// centroid[i] = (floor(sum_x / mass), floor(sum_y / mass)) or (-1, -1) for an empty mask
+__global__ void mask_centroids(const unsigned long long* __restrict__ sums, const int* __restrict__ total, int n_max,
+                               int* __restrict__ cent, int* __restrict__ mass_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_max || i >= *total) return;
+    const unsigned long long m = sums[i * 3];
+    mass_out[i] = (int)m;
+    cent[i * 2 + 0] = m ? (int)(sums[i * 3 + 1] / m) : -1;
+    cent[i * 2 + 1] = m ? (int)(sums[i * 3 + 2] / m) : -1;
+}
+
+// grid (n_max [mask i], kd [j-th detection of the same image]); closest[i][jl] = (x, y) 1-based, or (-1,-1).
+__global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict__ bits_all, const int* __restrict__ rect,
+                                                      const int* __restrict__ valid, const int* __restrict__ cent,
+                                                      const int* __restrict__ img, const int* __restrict__ offset,
+                                                      const int* __restrict__ total, int kd, int out_h, int out_w,
+                                                      int words_per_row, int* __restrict__ closest) {
+    __shared__ unsigned long long best[4];
+    const int i = blockIdx.x, jl = blockIdx.y;
+    const int n = *total;
+    if (i >= n) return;
+    const int j = offset[img[i]] + jl;
+    if (j >= offset[img[i] + 1]) return;
+    int* o = closest + ((size_t)i * kd + jl) * 2;
+    if (!valid[i] || cent[j * 2] < 0) {
+        if (threadIdx.x == 0) { o[0] = -1; o[1] = -1; }
+        return;
+    }
+    const float px = (float)cent[j * 2], py = (float)cent[j * 2 + 1];
+    const int rx0 = rect[i * 4 + 0], ry0 = rect[i * 4 + 1], rx1 = rect[i * 4 + 2], ry1 = rect[i * 4 + 3];
+    const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
+    const int nw = w1 - w0, nrows = ry1 - ry0;
+    const uint64_t* bits = bits_all + (size_t)i * out_h * words_per_row;
+    unsigned long long b = ~0ull;
+    for (int t = threadIdx.x; t < nw * nrows; t += blockDim.x) {
+        const int ry = t / nw, w = w0 + (t - ry * nw);
+        const int y = ry0 + ry;
+        uint64_t word = bits[(size_t)y * words_per_row + w];
+        const float dy = (float)(y + 1) - py;
+        const float dy2 = dy * dy;
+        while (word) {
+            const int bit = __ffsll((long long)word) - 1;
+            word &= word - 1;
+            const int x = (w << 6) + bit;
+            const float dx = (float)(x + 1) - px;
+            const float d = dx * dx + dy2;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(y * out_w + x);
+            b = key < b ? key : b;
+        }
+    }
+    for (int k = 32; k > 0; k >>= 1) { const unsigned long long other = __shfl_xor(b, k); b = other < b ? other : b; }
+    if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) b = best[k] < b ? best[k] : b;
+        if (b == ~0ull) { o[0] = -1; o[1] = -1; }
+        else {
+            const unsigned lin = (unsigned)(b & 0xffffffffu);
+            o[0] = (int)(lin % (unsigned)out_w) + 1;
+            o[1] = (int)(lin / (unsigned)out_w) + 1;
+        }
+    }
+}
+
+// Expand one detection's packed bits to a dense bool (uint8) frame: the reference's pred_masks view.
+__global__ __launch_bounds__(256) void bits_to_dense(const uint64_t* __restrict__ bits, const int* __restrict__ rect4,
+                                                     int out_h, int out_w, int words_per_row, uint8_t* __restrict__ dense) {
+    const size_t total = (size_t)out_h * out_w;
+    const int rx0 = rect4[0], ry0 = rect4[1], rx1 = rect4[2], ry1 = rect4[3];
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(e / out_w), x = (int)(e - (size_t)y * out_w);
+        uint8_t v = 0;
+        if (x >= rx0 && x < rx1 && y >= ry0 && y < ry1) v = (bits[(size_t)y * words_per_row + (x >> 6)] >> (x & 63)) & 1ull;
+        dense[e] = v;
+    }
+}
+
+// Dense bool frame (any mask, e.g. user supplied) -> packed bits + rect = full frame; sums accumulated.
+__global__ __launch_bounds__(256) void dense_to_bits(const uint8_t* __restrict__ dense, int out_h, int out_w,
+                                                     int words_per_row, uint64_t* __restrict__ bits,
+                                                     unsigned long long* __restrict__ sums) {
+    const int lane = threadIdx.x & 63;
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwords = out_h * words_per_row;
+    unsigned long long mass = 0, sx = 0, sy = 0;
+    for (int wi = gw; wi < nwords; wi += (gridDim.x * blockDim.x) >> 6) {
+        const int y = wi / words_per_row, w = wi - y * words_per_row;
+        const int x = (w << 6) + lane;
+        const bool on = x < out_w && dense[(size_t)y * out_w + x] != 0;
+        const uint64_t word = __ballot(on);
+        if (lane == 0) bits[wi] = word;
+        if (on) { mass += 1; sx += (unsigned long long)(x + 1); sy += (unsigned long long)(y + 1); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { mass += __shfl_xor(mass, o); sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); }
+    if (lane == 0 && mass) { atomicAdd(sums, mass); atomicAdd(sums + 1, sx); atomicAdd(sums + 2, sy); }
+}
+
+// Closest point of ONE packed mask (full-frame rect) to an explicit target (stateless op for mask_utils).
+__global__ __launch_bounds__(256) void closest_point_single(const uint64_t* __restrict__ bits, int out_h, int out_w,
+                                                            int words_per_row, float px, float py,
+                                                            unsigned long long* __restrict__ best_out) {
+    unsigned long long b = ~0ull;
+    const int nwords = out_h * words_per_row;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nwords; t += gridDim.x * blockDim.x) {
+        const int y = t / words_per_row, w = t - y * words_per_row;
+        uint64_t word = bits[t];
+        const float dy = (float)(y + 1) - py;
+        const float dy2 = dy * dy;
+        while (word) {
+            const int bit = __ffsll((long long)word) - 1;
+            word &= word - 1;
+            const int x = (w << 6) + bit;
+            const float dx = (float)(x + 1) - px;
+            const float d = dx * dx + dy2;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(y * out_w + x);
+            b = key < b ? key : b;
+        }
+    }
+    for (int k = 32; k > 0; k >>= 1) { const unsigned long long other = __shfl_xor(b, k); b = other < b ? other : b; }
+    if ((threadIdx.x & 63) == 0 && b != ~0ull) atomicMin(best_out, b);
+}
+
+extern "C" {
+int apse_k_closest_single(const uint64_t* bits, int out_h, int out_w, int words_per_row, float px, float py,
+                          unsigned long long* best_out, hipStream_t s) {
+    hipMemsetAsync(best_out, 0xff, sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(closest_point_single, dim3(512), dim3(256), 0, s, bits, out_h, out_w, words_per_row, px, py, best_out);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_mask_paste(const PasteParams* p, int n_max, int* cent, int* mass, hipStream_t s) {
+    if (n_max <= 0) return APSE_OK;
+    if (p->M > 32) return APSE_E_INVALID;
+    hipMemsetAsync(p->sums, 0, (size_t)n_max * 3 * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(det_postprocess, dim3((n_max + 63) / 64), dim3(64), 0, s, *p, n_max);
+    hipLaunchKernelGGL(paste_masks, dim3(n_max, PASTE_ROWSPLIT), dim3(256), 0, s, *p, n_max);
+    hipLaunchKernelGGL(mask_centroids, dim3((n_max + 63) / 64), dim3(64), 0, s, p->sums, p->total, n_max, cent, mass);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_closest_points(const uint64_t* bits, const int* rect, const int* valid, const int* cent, const int* img,
+                          const int* offset, const int* total, int n_max, int kd, int out_h, int out_w, int words_per_row,
+                          int* closest, hipStream_t s) {
+    if (n_max <= 0) return APSE_OK;
+    hipLaunchKernelGGL(closest_points, dim3(n_max, kd), dim3(256), 0, s, bits, rect, valid, cent, img, offset, total, kd, out_h,
+                       out_w, words_per_row, closest);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_bits_to_dense(const uint64_t* bits, const int* rect4, int out_h, int out_w, int words_per_row, uint8_t* dense,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(bits_to_dense, dim3(2048), dim3(256), 0, s, bits, rect4, out_h, out_w, words_per_row, dense);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_dense_to_bits(const uint8_t* dense, int out_h, int out_w, int words_per_row, uint64_t* bits,
+                         unsigned long long* sums, hipStream_t s) {
+    hipMemsetAsync(sums, 0, 3 * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(dense_to_bits, dim3(1024), dim3(256), 0, s, dense, out_h, out_w, words_per_row, bits, sums);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+}

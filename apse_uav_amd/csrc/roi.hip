@@ -1,0 +1,172 @@
+// ROI gather kernels (gfx950), NHWC f32 feature maps with C = 256 (one wave = 64 lanes x float4).
+//  * roi_align_nhwc : detectron2 ROIPooler + ROIAlign(aligned=True, sampling_ratio=0) over p2..p5
+//                     (box head 7x7, mask head 14x14; reached from dcnn/networks/track_rcnn.py:51)
+//  * roi_pool_nhwc  : torchvision.ops.roi_pool on p2 (dcnn/engines/rcnn_tracker.py:182)
+//  * l2_normalize, sqdist_matrix : AssociationHead's F.normalize (dcnn/networks/association_head.py:25)
+//                     and RcnnTracker.calculate_distance_matrix (dcnn/engines/rcnn_tracker.py:192-221)
+// Output layout is [roi][ph][pw][C]; the consuming FC weights are permuted (c,h,w)->(h,w,c) at load.
+#include "apse_common.h"
+#include <float.h>
+
+struct FpnMaps {
+    const float* p[4];     // p2..p5, each [B][H][W][256]
+    int H[4], W[4];
+    float scale[4];        // 1/4 .. 1/32
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// One wave per output bin.  rois: [n_max][4]; image of roi r: roi_img ? roi_img[r] : r / per_img.
+// live rois: (roi_img ? r < *total : (r % per_img) < cnt[r / per_img]); dead rois write zeros.
+__global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const float* __restrict__ rois,
+                                                      const int* __restrict__ roi_img, const int* __restrict__ cnt,
+                                                      const int* __restrict__ total, int per_img, int n_max, int R,
+                                                      float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int bin = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rr = R * R;
+    const int r = bin / rr;
+    if (r >= n_max) return;
+    const int pb = bin - r * rr;
+    const int ph = pb / R, pw = pb - ph * R;
+    int img;
+    bool live;
+    if (roi_img) {
+        live = r < *total;
+        img = live ? roi_img[r] : 0;
+    } else {
+        img = r / per_img;
+        live = (r - img * per_img) < cnt[img];
+    }
+    float* o = out + ((size_t)r * rr + pb) * 256 + lane * 4;
+    if (!live) {
+        if (roi_img) return;             // packed list: rows past the count are never read
+        *reinterpret_cast<f32x4*>(o) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const float x1 = rois[r * 4 + 0], y1 = rois[r * 4 + 1], x2 = rois[r * 4 + 2], y2 = rois[r * 4 + 3];
+    // assign_boxes_to_levels: floor(4 + log2(sqrt(area) / 224 + eps)), clamped to [2, 5]
+    const float sz = sqrtf((x2 - x1) * (y2 - y1));
+    float lvf = floorf(4.0f + log2f(sz / 224.0f + 2.220446049250313e-16f));
+    lvf = fminf(fmaxf(lvf, 2.f), 5.f);
+    const int lv = (int)lvf - 2;
+    const int H = F.H[lv], W = F.W[lv];
+    const float sc = F.scale[lv];
+    const float* f = F.p[lv] + (size_t)img * H * W * 256 + lane * 4;
+    const float sw = x1 * sc - 0.5f, sh = y1 * sc - 0.5f;
+    const float ew = x2 * sc - 0.5f, eh = y2 * sc - 0.5f;
+    const float rw = ew - sw, rh = eh - sh;
+    const float bw = rw / (float)R, bh = rh / (float)R;
+    const int gh = (int)ceilf(rh / (float)R), gw = (int)ceilf(rw / (float)R);
+    const float cntf = (float)((gh * gw) > 1 ? gh * gw : 1);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int iy = 0; iy < gh; ++iy) {
+        float y = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+        if (y < -1.0f || y > (float)H) continue;
+        if (y <= 0.f) y = 0.f;
+        int yl = (int)y, yh;
+        if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else { yh = yl + 1; }
+        const float ly = y - (float)yl, hy = 1.f - ly;
+        for (int ix = 0; ix < gw; ++ix) {
+            float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+            if (x < -1.0f || x > (float)W) continue;
+            if (x <= 0.f) x = 0.f;
+            int xl = (int)x, xh;
+            if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
+            const float lx = x - (float)xl, hx = 1.f - lx;
+            const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+            const f32x4 v1 = ld4(f + ((size_t)yl * W + xl) * 256);
+            const f32x4 v2 = ld4(f + ((size_t)yl * W + xh) * 256);
+            const f32x4 v3 = ld4(f + ((size_t)yh * W + xl) * 256);
+            const f32x4 v4 = ld4(f + ((size_t)yh * W + xh) * 256);
+            acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+        }
+    }
+    *reinterpret_cast<f32x4*>(o) = acc / cntf;
+}
+
+// torchvision roi_pool forward on one NHWC map; rois in original-frame pixels, packed list.
+__global__ __launch_bounds__(256) void roi_pool_nhwc(const float* __restrict__ feat, int H, int W,
+                                                     const float* __restrict__ rois, const int* __restrict__ roi_img,
+                                                     const int* __restrict__ total, int n_max, int R, float scale,
+                                                     float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int bin = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rr = R * R;
+    const int r = bin / rr;
+    if (r >= n_max || r >= *total) return;
+    const int pb = bin - r * rr;
+    const int ph = pb / R, pw = pb - ph * R;
+    const float* f = feat + (size_t)roi_img[r] * H * W * 256 + lane * 4;
+    const int sw = (int)roundf(rois[r * 4 + 0] * scale), sh = (int)roundf(rois[r * 4 + 1] * scale);
+    const int ew = (int)roundf(rois[r * 4 + 2] * scale), eh = (int)roundf(rois[r * 4 + 3] * scale);
+    const int rw = (ew - sw + 1) > 1 ? (ew - sw + 1) : 1;
+    const int rh = (eh - sh + 1) > 1 ? (eh - sh + 1) : 1;
+    const float bh = (float)rh / (float)R, bw = (float)rw / (float)R;
+    int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);
+    int ws = (int)floorf((float)pw * bw), we = (int)ceilf((float)(pw + 1) * bw);
+    hs = min(max(hs + sh, 0), H); he = min(max(he + sh, 0), H);
+    ws = min(max(ws + sw, 0), W); we = min(max(we + sw, 0), W);
+    const bool empty = (he <= hs) || (we <= ws);
+    const float init = empty ? 0.f : -FLT_MAX;
+    f32x4 m = {init, init, init, init};
+    for (int y = hs; y < he; ++y)
+        for (int x = ws; x < we; ++x) {
+            const f32x4 v = ld4(f + ((size_t)y * W + x) * 256);
+            m[0] = v[0] > m[0] ? v[0] : m[0];
+            m[1] = v[1] > m[1] ? v[1] : m[1];
+            m[2] = v[2] > m[2] ? v[2] : m[2];
+            m[3] = v[3] > m[3] ? v[3] : m[3];
+        }
+    *reinterpret_cast<f32x4*>(out + ((size_t)r * rr + pb) * 256 + lane * 4) = m;
+}
+
+// F.normalize(x, p=2, dim=1, eps=1e-12) on [n][D] rows, one wave per row (D <= 256, D % 64 == 0 not required).
+__global__ __launch_bounds__(64) void l2_normalize_rows(const float* __restrict__ x, float* __restrict__ y, int D,
+                                                        const int* __restrict__ total, int n_max) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= n_max || (total && r >= *total)) return;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) { const float v = x[(size_t)r * D + i]; s += v * v; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    float nrm = sqrtf(s);
+    nrm = nrm < 1e-12f ? 1e-12f : nrm;
+    for (int i = lane; i < D; i += 64) y[(size_t)r * D + i] = x[(size_t)r * D + i] / nrm;
+}
+
+// D[o][n] = sum_k (a[o][k] - b[n][k])^2, one wave per pair.
+__global__ __launch_bounds__(64) void sqdist_matrix(const float* __restrict__ a, const float* __restrict__ b, int O, int N,
+                                                    int D, float* __restrict__ out) {
+    const int o = blockIdx.y, n = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) { const float d = a[(size_t)o * D + i] - b[(size_t)n * D + i]; s += d * d; }
+    for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
+    if (lane == 0) out[(size_t)o * N + n] = s;
+}
+
+extern "C" {
+int apse_k_roi_align(const FpnMaps* F, const float* rois, const int* roi_img, const int* cnt, const int* total, int per_img,
+                     int n_max, int R, float* out, hipStream_t s) {
+    const int bins = n_max * R * R;
+    hipLaunchKernelGGL(roi_align_nhwc, dim3((bins + 3) / 4), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R,
+                       out);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_roi_pool(const float* feat, int H, int W, const float* rois, const int* roi_img, const int* total, int n_max,
+                    int R, float scale, float* out, hipStream_t s) {
+    const int bins = n_max * R * R;
+    hipLaunchKernelGGL(roi_pool_nhwc, dim3((bins + 3) / 4), dim3(256), 0, s, feat, H, W, rois, roi_img, total, n_max, R, scale,
+                       out);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_l2_normalize(const float* x, float* y, int D, const int* total, int n_max, hipStream_t s) {
+    if (n_max <= 0) return APSE_OK;
+    hipLaunchKernelGGL(l2_normalize_rows, dim3(n_max), dim3(64), 0, s, x, y, D, total, n_max);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_sqdist(const float* a, const float* b, int O, int N, int D, float* out, hipStream_t s) {
+    if (O <= 0 || N <= 0) return APSE_OK;
+    hipLaunchKernelGGL(sqdist_matrix, dim3(N, O), dim3(64), 0, s, a, b, O, N, D, out);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+}

@@ -1,0 +1,458 @@
+// Decision kernels of the dcnn hot path (gfx950): top-k, box decoding, NMS, final ranking.
+// Everything here is f32 with -ffp-contract=off so that, given identical inputs, the index
+// results are identical to the CPU oracle's (each product and sum rounded separately, IEEE
+// division).  Ordering rule everywhere: score descending, ties by ascending input index
+// (DESIGN.md "Tie-breaks").
+//
+// Restates (from detectron2 0.1.2 / torchvision 0.6, reached from
+// /root/reference/dcnn/networks/track_rcnn.py:46,51):
+//   RPNOutputs.predict_proposals + find_top_rpn_proposals  -> rpn_topk_stage, rpn_decode,
+//                                                             nms_percat, rank_final
+//   FastRCNNOutputs.inference / fast_rcnn_inference_single_image -> box_candidates,
+//                                                             nms_percat, rank_final
+#include "apse_common.h"
+
+#define TK_N 4096          // elements sorted per block in the top-k tournament
+#define NMS_MAX 1024       // boxes per category (<= 1000 by construction)
+#define RANK_N 8192        // final ranking capacity
+
+__device__ __forceinline__ uint32_t mono_key(float f) {   // order-preserving float -> uint
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float mono_inv(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+// ascending sort of this composite = score descending, index ascending
+__device__ __forceinline__ uint64_t comp_key(float score, uint32_t idx) {
+    return ((uint64_t)(~mono_key(score)) << 32) | idx;
+}
+__device__ __forceinline__ float comp_score(uint64_t k) { return mono_inv(~(uint32_t)(k >> 32)); }
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {   // l must be wave-uniform
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int N, int THREADS>
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int tid) {
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < N; i += THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool asc = (i & k) == 0;
+                    const uint64_t x = a[i], y = a[ixj];
+                    if ((x > y) == asc) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------- RPN top-k tournament
+struct RpnLevel {
+    const float* head;     // [B][H*W][head_ld] : channels 0..2 objectness, 3..14 deltas (a*4+coord)
+    int H, W, stride;
+    int n;                 // H*W*3
+    int k;                 // min(pre_topk, n)
+    float base[3][4];      // cell anchors (x0,y0,x1,y1)
+};
+struct RpnLevels {
+    RpnLevel lv[5];
+    int head_ld;
+    int pre_topk;          // 1000
+};
+struct TopkJob {
+    int kind;              // 0: raw logits chunk, 1: merge of lists
+    int level;
+    int begin, count;      // kind 0: element range within the level
+    int nsrc;
+    int src[4];            // kind 1: source list slots
+    int src_count[4];
+    int dst;               // destination list slot
+    int dst_count;         // min(pre_topk, total)
+};
+
+// lists: [B][nslots][1024] u64
+__global__ __launch_bounds__(1024) void rpn_topk_stage(const RpnLevels* __restrict__ Lp, const TopkJob* __restrict__ jobs,
+                                                       uint64_t* __restrict__ lists, int nslots) {
+    __shared__ uint64_t a[TK_N];
+    const TopkJob* job = jobs + blockIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    uint64_t* pool = lists + (size_t)b * nslots * 1024;
+    if (job->kind == 0) {
+        const RpnLevel* lv = &Lp->lv[job->level];
+        const int head_ld = Lp->head_ld;
+        const float* head = lv->head + (size_t)b * lv->H * lv->W * head_ld;
+        const int jb = job->begin, jc = job->count;
+        for (int i = tid; i < TK_N; i += 1024) {
+            uint64_t k = ~0ull;
+            if (i < jc) {
+                const int e = jb + i;
+                const int pix = e / 3, an = e - pix * 3;
+                k = comp_key(head[(size_t)pix * head_ld + an], (uint32_t)e);
+            }
+            a[i] = k;
+        }
+    } else {
+        const int ns = job->nsrc;
+        for (int i = tid; i < TK_N; i += 1024) {
+            const int s = i >> 10, r = i & 1023;
+            uint64_t k = ~0ull;
+            if (s < ns && r < job->src_count[s]) k = pool[(size_t)job->src[s] * 1024 + r];
+            a[i] = k;
+        }
+    }
+    __syncthreads();
+    bitonic_sort_lds<TK_N, 1024>(a, tid);
+    if (tid < job->dst_count) pool[(size_t)job->dst * 1024 + tid] = a[tid];
+}
+
+// Decode the selected anchors of every level: Box2BoxTransform.apply_deltas (weights 1,1,1,1),
+// clip to the image, nonempty flag, and the running max coordinate of the kept boxes.
+// out arrays are [B][5*pre_topk].
+__global__ __launch_bounds__(256) void rpn_decode(const RpnLevels* __restrict__ Lp, const uint64_t* __restrict__ lists, int nslots,
+                                                  const int* __restrict__ final_slot, float img_h, float img_w,
+                                                  float scale_clamp, float* __restrict__ boxes, float* __restrict__ scores,
+                                                  int* __restrict__ valid, uint32_t* __restrict__ maxc) {
+    const int b = blockIdx.z, l = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pre_topk = Lp->pre_topk, head_ld = Lp->head_ld;
+    if (i >= pre_topk) return;
+    const RpnLevel lv = Lp->lv[l];
+    const size_t o = (size_t)b * 5 * pre_topk + (size_t)l * pre_topk + i;
+    if (i >= lv.k) { valid[o] = 0; scores[o] = 0.f; return; }
+    const uint64_t key = lists[((size_t)b * nslots + final_slot[l]) * 1024 + i];
+    const uint32_t e = (uint32_t)key;
+    const float sc = comp_score(key);
+    const int pix = e / 3, an = e - pix * 3;
+    const int y = pix / lv.W, x = pix - y * lv.W;
+    const float sx = (float)(x * lv.stride), sy = (float)(y * lv.stride);
+    const float ax0 = sx + lv.base[an][0], ay0 = sy + lv.base[an][1];
+    const float ax1 = sx + lv.base[an][2], ay1 = sy + lv.base[an][3];
+    const float* d = lv.head + ((size_t)b * lv.H * lv.W + pix) * head_ld + 3 + an * 4;
+    const float w = ax1 - ax0, h = ay1 - ay0;
+    const float cx = ax0 + 0.5f * w, cy = ay0 + 0.5f * h;
+    float dx = d[0] / 1.0f, dy = d[1] / 1.0f, dw = d[2] / 1.0f, dh = d[3] / 1.0f;
+    dw = dw > scale_clamp ? scale_clamp : dw;
+    dh = dh > scale_clamp ? scale_clamp : dh;
+    const float pcx = dx * w + cx, pcy = dy * h + cy;
+    const float pw = expf(dw) * w, ph = expf(dh) * h;
+    float x0 = pcx - 0.5f * pw, y0 = pcy - 0.5f * ph, x1 = pcx + 0.5f * pw, y1 = pcy + 0.5f * ph;
+    x0 = fminf(fmaxf(x0, 0.f), img_w);
+    y0 = fminf(fmaxf(y0, 0.f), img_h);
+    x1 = fminf(fmaxf(x1, 0.f), img_w);
+    y1 = fminf(fmaxf(y1, 0.f), img_h);
+    const int ok = ((x1 - x0) > 0.f) && ((y1 - y0) > 0.f);
+    boxes[o * 4 + 0] = x0; boxes[o * 4 + 1] = y0; boxes[o * 4 + 2] = x1; boxes[o * 4 + 3] = y1;
+    scores[o] = sc;
+    valid[o] = ok;
+    if (ok) {
+        const float m = fmaxf(fmaxf(x0, x1), fmaxf(y0, y1));   // all >= 0 after the clip
+        atomicMax(maxc + b, __float_as_uint(m));
+    }
+}
+
+// ---------------------------------------------------------------- per-category NMS
+// One block per (category, image).  Entries: boxes/scores/valid are [B][n_total]; the category of
+// entry e is  cat_div ? e / cat_div : e % cat_mod .  Within the category, entries are ordered by
+// (score desc, entry index asc), IoU is evaluated on boxes shifted by cat * (max_coord + 1) in f32
+// (torchvision batched_nms), `iou > thr` suppresses.  Output: kept entry indices in that order.
+__global__ __launch_bounds__(1024) void nms_percat(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                   const int* __restrict__ valid, int n_total, int cat_div, int cat_mod,
+                                                   const uint32_t* __restrict__ maxc, float thr, int* __restrict__ keep_idx,
+                                                   int* __restrict__ keep_cnt, int ncat, const int* __restrict__ n_limit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* mask = reinterpret_cast<uint64_t*>(smem);                      // [NMS_MAX][16]  (128 KB)
+    uint64_t* keys = mask + (size_t)NMS_MAX * 16;                            // [NMS_MAX]      (8 KB)
+    float* bx = reinterpret_cast<float*>(keys + NMS_MAX);                    // [4][NMS_MAX]   (16 KB)
+    float* area = bx + 4 * NMS_MAX;                                          // [NMS_MAX]      (4 KB)
+    int* wsum = reinterpret_cast<int*>(area + NMS_MAX);                      // [17]
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    boxes += (size_t)b * n_total * 4;
+    scores += (size_t)b * n_total;
+    valid += (size_t)b * n_total;
+    int nt = n_total;
+    if (n_limit) { const int lim = n_limit[b]; nt = lim < nt ? lim : nt; }
+
+    // 1. ordered compaction of this category's valid entries
+    if (tid == 0) wsum[16] = 0;
+    for (int i = tid; i < NMS_MAX; i += 1024) keys[i] = ~0ull;
+    __syncthreads();
+    for (int base = 0; base < nt; base += 1024) {
+        const int e = base + tid;
+        bool f = false;
+        if (e < nt) {
+            const int cat = cat_div ? e / cat_div : e % cat_mod;
+            f = (cat == c) && valid[e];
+        }
+        const uint64_t bal = __ballot(f);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = wsum[16];
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+        if (f && pos < NMS_MAX) keys[pos] = comp_key(scores[e], (uint32_t)e);
+        __syncthreads();
+        if (tid == 0) { int t = wsum[16]; for (int w = 0; w < 16; ++w) t += wsum[w]; wsum[16] = t; }
+        __syncthreads();
+    }
+    int n = wsum[16];
+    n = n < NMS_MAX ? n : NMS_MAX;
+    // 2. sort by (score desc, index asc)
+    bitonic_sort_lds<NMS_MAX, 1024>(keys, tid);
+    // 3. shifted boxes + areas
+    const float off = (float)c * (__uint_as_float(maxc[b]) + 1.0f);
+    if (tid < n) {
+        const uint32_t e = (uint32_t)keys[tid];
+        const float x0 = boxes[e * 4 + 0] + off, y0 = boxes[e * 4 + 1] + off;
+        const float x1 = boxes[e * 4 + 2] + off, y1 = boxes[e * 4 + 3] + off;
+        bx[tid] = x0; bx[NMS_MAX + tid] = y0; bx[2 * NMS_MAX + tid] = x1; bx[3 * NMS_MAX + tid] = y1;
+        area[tid] = (x1 - x0) * (y1 - y0);
+    }
+    __syncthreads();
+    // 4. suppression bit-matrix: mask[i][w] bit j  <=>  IoU(i, 64w+j) > thr, for 64w+j > i
+    const int nw = (n + 63) >> 6;
+    for (int item = tid; item < n * nw; item += 1024) {
+        const int i = item / nw, w = item - i * nw;
+        uint64_t bits = 0;
+        if (64 * w + 63 > i) {
+            const float ix0 = bx[i], iy0 = bx[NMS_MAX + i], ix1 = bx[2 * NMS_MAX + i], iy1 = bx[3 * NMS_MAX + i];
+            const float ia = area[i];
+            const int j0 = 64 * w;
+            const int jend = (n - j0) < 64 ? (n - j0) : 64;
+            for (int jj = 0; jj < jend; ++jj) {
+                const int j = j0 + jj;
+                if (j <= i) continue;
+                const float xx0 = fmaxf(ix0, bx[j]), yy0 = fmaxf(iy0, bx[NMS_MAX + j]);
+                const float xx1 = fminf(ix1, bx[2 * NMS_MAX + j]), yy1 = fminf(iy1, bx[3 * NMS_MAX + j]);
+                const float ww = fmaxf(0.f, xx1 - xx0), hh = fmaxf(0.f, yy1 - yy0);
+                const float inter = ww * hh;
+                const float ovr = inter / (ia + area[j] - inter);
+                if (ovr > thr) bits |= (1ull << jj);
+            }
+        }
+        mask[(size_t)i * 16 + w] = bits;
+    }
+    __syncthreads();
+    // 5. greedy scan (wave 0): 64 rows at a time; the in-chunk dependency is resolved on the
+    //    diagonal word with scalar reads, then the kept rows' words are OR-reduced into `removed`.
+    if (wave == 0) {
+        uint64_t removed = 0;          // lane w (< 16) owns word w of the removed bitmap
+        int kept = 0;
+        int* out = keep_idx + ((size_t)b * ncat + c) * NMS_MAX;
+        for (int ch = 0; ch < nw; ++ch) {
+            const int row = 64 * ch + lane;
+            const uint64_t diag = row < n ? mask[(size_t)row * 16 + ch] : 0ull;
+            uint64_t rem = readlane64(removed, ch);
+            uint64_t keepbits = 0;
+            const int rows_here = (n - 64 * ch) < 64 ? (n - 64 * ch) : 64;
+            for (int r = 0; r < rows_here; ++r) {
+                if (!((rem >> r) & 1ull)) {
+                    keepbits |= (1ull << r);
+                    rem |= readlane64(diag, r);
+                }
+            }
+            // write kept entries of this chunk in order
+            if ((keepbits >> lane) & 1ull) {
+                const int pos = kept + __popcll(keepbits & ((1ull << lane) - 1ull));
+                out[pos] = (int)(uint32_t)keys[row];
+            }
+            kept += __popcll(keepbits);
+            // removed[w] |= OR_{kept rows r} mask[64ch+r][w]   (lane = w)
+            if (lane < nw) {
+                uint64_t acc = 0;
+                for (int r = 0; r < rows_here; ++r)
+                    if ((keepbits >> r) & 1ull) acc |= mask[(size_t)(64 * ch + r) * 16 + lane];
+                removed |= acc;
+            }
+        }
+        if (lane == 0) keep_cnt[b * ncat + c] = kept;
+    }
+}
+
+// Final ranking: all kept entries of all categories by (score desc, entry index asc); first K.
+// Writes boxes/scores/entry index of the winners and their count.
+__global__ __launch_bounds__(1024) void rank_final(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                   int n_total, const int* __restrict__ keep_idx,
+                                                   const int* __restrict__ keep_cnt, int ncat, int K,
+                                                   float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                   int* __restrict__ out_entry, int* __restrict__ out_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* a = reinterpret_cast<uint64_t*>(smem);    // [RANK_N]
+    __shared__ int total;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    boxes += (size_t)b * n_total * 4;
+    scores += (size_t)b * n_total;
+    for (int i = tid; i < RANK_N; i += 1024) a[i] = ~0ull;
+    __syncthreads();
+    int base = 0;
+    for (int c = 0; c < ncat; ++c) {
+        const int cnt = keep_cnt[b * ncat + c];
+        const int* src = keep_idx + ((size_t)b * ncat + c) * NMS_MAX;
+        for (int i = tid; i < cnt; i += 1024) {
+            const int e = src[i];
+            if (base + i < RANK_N) a[base + i] = comp_key(scores[e], (uint32_t)e);
+        }
+        base += cnt;
+    }
+    if (tid == 0) total = base < RANK_N ? base : RANK_N;
+    __syncthreads();
+    bitonic_sort_lds<RANK_N, 1024>(a, tid);
+    const int n = total < K ? total : K;
+    for (int i = tid; i < K; i += 1024) {
+        float* ob = out_boxes + ((size_t)b * K + i) * 4;
+        if (i < n) {
+            const uint32_t e = (uint32_t)a[i];
+            ob[0] = boxes[e * 4 + 0]; ob[1] = boxes[e * 4 + 1]; ob[2] = boxes[e * 4 + 2]; ob[3] = boxes[e * 4 + 3];
+            out_scores[(size_t)b * K + i] = scores[e];
+            out_entry[(size_t)b * K + i] = (int)e;
+        } else {
+            ob[0] = ob[1] = ob[2] = ob[3] = 0.f;
+            out_scores[(size_t)b * K + i] = 0.f;
+            out_entry[(size_t)b * K + i] = -1;
+        }
+    }
+    if (tid == 0) out_count[b] = n;
+}
+
+// ---------------------------------------------------------------- box head post-processing
+// One thread per ROI: softmax over K+1 logits, per-class box decoding (weights wx,wy,ww,wh), clip,
+// score filter.  pred: [B*P][ld] with logits at [0..K] (background last) and deltas at [K+1 ..].
+// Candidate slot = roi*K + class (== torch nonzero() order).
+__global__ __launch_bounds__(256) void box_candidates(const float* __restrict__ pred, int ld, int K,
+                                                      const float* __restrict__ props, const int* __restrict__ prop_cnt,
+                                                      int P, float img_h, float img_w, float thresh, float wx, float wy,
+                                                      float ww, float wh, float scale_clamp, float* __restrict__ cboxes,
+                                                      float* __restrict__ cscores, int* __restrict__ cvalid,
+                                                      uint32_t* __restrict__ maxc, float* __restrict__ probs_out) {
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P) return;
+    const size_t roi = (size_t)b * P + r;
+    const bool live = r < prop_cnt[b];
+    const float* lg = pred + roi * ld;
+    float mx = lg[0];
+    for (int k = 1; k <= K; ++k) mx = fmaxf(mx, lg[k]);
+    float ex[8], sum = 0.f;
+    for (int k = 0; k <= K; ++k) { ex[k] = expf(lg[k] - mx); sum += ex[k]; }
+    const float* pb = props + roi * 4;
+    const float w = pb[2] - pb[0], h = pb[3] - pb[1];
+    const float cx = pb[0] + 0.5f * w, cy = pb[1] + 0.5f * h;
+    for (int k = 0; k < K; ++k) {
+        const size_t slot = roi * K + k;
+        const float p = ex[k] / sum;
+        if (probs_out) probs_out[roi * (K + 1) + k] = p;
+        const float* d = lg + (K + 1) + 4 * k;
+        float dx = d[0] / wx, dy = d[1] / wy, dw = d[2] / ww, dh = d[3] / wh;
+        dw = dw > scale_clamp ? scale_clamp : dw;
+        dh = dh > scale_clamp ? scale_clamp : dh;
+        const float pcx = dx * w + cx, pcy = dy * h + cy;
+        const float pw = expf(dw) * w, ph = expf(dh) * h;
+        float x0 = pcx - 0.5f * pw, y0 = pcy - 0.5f * ph, x1 = pcx + 0.5f * pw, y1 = pcy + 0.5f * ph;
+        x0 = fminf(fmaxf(x0, 0.f), img_w);
+        y0 = fminf(fmaxf(y0, 0.f), img_h);
+        x1 = fminf(fmaxf(x1, 0.f), img_w);
+        y1 = fminf(fmaxf(y1, 0.f), img_h);
+        const int ok = live && (p > thresh);
+        cboxes[slot * 4 + 0] = x0; cboxes[slot * 4 + 1] = y0; cboxes[slot * 4 + 2] = x1; cboxes[slot * 4 + 3] = y1;
+        cscores[slot] = p;
+        cvalid[slot] = ok;
+        if (ok) atomicMax(maxc + b, __float_as_uint(fmaxf(fmaxf(x0, x1), fmaxf(y0, y1))));
+    }
+    if (probs_out) probs_out[roi * (K + 1) + K] = ex[K] / sum;
+}
+
+// Pack per-image detections into one dense list (image id kept per entry) so the mask tail's
+// GEMMs see a contiguous M.  det_* are [B][Kd]; packed_* are [B*Kd].
+__global__ void pack_detections(const float* __restrict__ det_boxes, const float* __restrict__ det_scores,
+                                const int* __restrict__ det_entry, const int* __restrict__ det_cnt, int B, int Kd,
+                                int ncls, float* __restrict__ pk_boxes, float* __restrict__ pk_scores,
+                                int* __restrict__ pk_cls, int* __restrict__ pk_img, int* __restrict__ pk_roi,
+                                int* __restrict__ pk_total, int* __restrict__ pk_offset) {
+    __shared__ int offs[65];
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int b = 0; b < B; ++b) { offs[b] = t; pk_offset[b] = t; t += det_cnt[b]; }
+        offs[B] = t;
+        pk_offset[B] = t;
+        *pk_total = t;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B * Kd; i += blockDim.x) {
+        const int b = i / Kd, k = i - b * Kd;
+        if (k < det_cnt[b]) {
+            const int o = offs[b] + k;
+            const float* s = det_boxes + (size_t)i * 4;
+            pk_boxes[o * 4 + 0] = s[0]; pk_boxes[o * 4 + 1] = s[1]; pk_boxes[o * 4 + 2] = s[2]; pk_boxes[o * 4 + 3] = s[3];
+            pk_scores[o] = det_scores[i];
+            const int e = det_entry[i];
+            pk_cls[o] = e % ncls;
+            pk_roi[o] = e / ncls;
+            pk_img[o] = b;
+        }
+    }
+}
+
+extern "C" {
+int apse_k_rpn_topk_stage(const RpnLevels* L_dev, const TopkJob* jobs_dev, int njobs, uint64_t* lists, int nslots, int B,
+                          hipStream_t s) {
+    if (njobs <= 0) return APSE_OK;
+    hipLaunchKernelGGL(rpn_topk_stage, dim3(njobs, B), dim3(1024), 0, s, L_dev, jobs_dev, lists, nslots);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_rpn_decode(const RpnLevels* L_dev, int pre_topk, const uint64_t* lists, int nslots, const int* final_slot_dev,
+                      float img_h, float img_w, float scale_clamp, float* boxes, float* scores, int* valid, uint32_t* maxc,
+                      int B, hipStream_t s) {
+    hipLaunchKernelGGL(rpn_decode, dim3((pre_topk + 255) / 256, 5, B), dim3(256), 0, s, L_dev, lists, nslots, final_slot_dev,
+                       img_h, img_w, scale_clamp, boxes, scores, valid, maxc);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+static size_t nms_lds_bytes() { return (size_t)NMS_MAX * 16 * 8 + NMS_MAX * 8 + 5 * NMS_MAX * 4 + 32 * 4; }
+int apse_k_nms_percat(const float* boxes, const float* scores, const int* valid, int n_total, int cat_div, int cat_mod,
+                      const uint32_t* maxc, float thr, int* keep_idx, int* keep_cnt, int ncat, const int* n_limit, int B,
+                      hipStream_t s) {
+    static bool done = false;
+    if (!done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_percat), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)nms_lds_bytes());
+        done = true;
+    }
+    hipLaunchKernelGGL(nms_percat, dim3(ncat, B), dim3(1024), nms_lds_bytes(), s, boxes, scores, valid, n_total, cat_div,
+                       cat_mod, maxc, thr, keep_idx, keep_cnt, ncat, n_limit);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_rank_final(const float* boxes, const float* scores, int n_total, const int* keep_idx, const int* keep_cnt,
+                      int ncat, int K, float* out_boxes, float* out_scores, int* out_entry, int* out_count, int B,
+                      hipStream_t s) {
+    static bool done = false;
+    if (!done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_final), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            RANK_N * 8);
+        done = true;
+    }
+    hipLaunchKernelGGL(rank_final, dim3(B), dim3(1024), RANK_N * 8, s, boxes, scores, n_total, keep_idx, keep_cnt, ncat, K,
+                       out_boxes, out_scores, out_entry, out_count);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_box_candidates(const float* pred, int ld, int K, const float* props, const int* prop_cnt, int P, float img_h,
+                          float img_w, float thresh, const float* wts, float scale_clamp, float* cboxes, float* cscores,
+                          int* cvalid, uint32_t* maxc, float* probs_out, int B, hipStream_t s) {
+    if (K > 7) return APSE_E_INVALID;
+    hipLaunchKernelGGL(box_candidates, dim3((P + 255) / 256, B), dim3(256), 0, s, pred, ld, K, props, prop_cnt, P, img_h,
+                       img_w, thresh, wts[0], wts[1], wts[2], wts[3], scale_clamp, cboxes, cscores, cvalid, maxc, probs_out);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_pack_detections(const float* det_boxes, const float* det_scores, const int* det_entry, const int* det_cnt, int B,
+                           int Kd, int ncls, float* pk_boxes, float* pk_scores, int* pk_cls, int* pk_img, int* pk_roi,
+                           int* pk_total, int* pk_offset, hipStream_t s) {
+    if (B > 64) return APSE_E_INVALID;
+    hipLaunchKernelGGL(pack_detections, dim3(1), dim3(256), 0, s, det_boxes, det_scores, det_entry, det_cnt, B, Kd, ncls,
+                       pk_boxes, pk_scores, pk_cls, pk_img, pk_roi, pk_total, pk_offset);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+}

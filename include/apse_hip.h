@@ -1,0 +1,174 @@
+/* apse_hip.h -- C ABI of libapse_hip.so: the MI355X (gfx950) implementation of the per-frame
+ * hot path of vision-agh/apse_uav's dcnn/ subsystem.
+ *
+ * The reference has no FFI layer: its boundary is the Python surface
+ *   dcnn/engines/track_predictor.py:31-52  TrackPredictor.__call__   (resize + TrackRCNN.inference)
+ *   dcnn/networks/track_rcnn.py:16-58      TrackRCNN.inference       (preprocess, backbone+FPN, RPN, ROI heads, postprocess)
+ *   dcnn/engines/rcnn_tracker.py:156-221   get_features_rois, association head, distance matrix
+ *   dcnn/utils/mask_utils.py:6-38          get_mask_centroid, compute_closest_point
+ * Each entry point below names the reference code it replaces.  apse_uav_amd/_lib.py is the ctypes
+ * binding; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 (APSE_OK) or a negative APSE_E_* code; apse_last_error()
+ * gives the text.  Pointers named *_dev are device pointers owned by the caller; `stream` is a
+ * hipStream_t passed as void*.  Calls enqueue work and return; only apse_read_results synchronises.
+ * A context is bound to one device and is not thread-safe (one per process rank).
+ */
+#ifndef APSE_HIP_H
+#define APSE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APSE_OK 0
+#define APSE_E_INVALID (-1)
+#define APSE_E_HIP (-2)
+#define APSE_E_NOMEM (-3)
+#define APSE_E_STATE (-4)
+#define APSE_E_MISSING (-5)
+
+typedef struct apse_ctx apse_ctx;
+
+/* Hyper-parameters that define results (dcnn/configs/Base-RCNN-FPN.yaml,
+ * dcnn/scripts/tests/visualize_uav.py:30-48, dcnn/engines/rcnn_tracker.py:33). */
+typedef struct apse_config {
+    int struct_size;              /* sizeof(apse_config), ABI check */
+    int device;
+    int max_batch;                /* frames per forward (reference: 1) */
+    int frame_h, frame_w;         /* original frame, e.g. 2160 x 3840 */
+    int image_h, image_w;         /* after ResizeShortestEdge, e.g. 750 x 1333 */
+    int blocks[4];                /* bottlenecks per stage, R-101 = 3,4,23,3 */
+    int num_classes;              /* 4 */
+    float score_thresh;           /* 0.5 */
+    float box_nms;                /* 0.5 */
+    float rpn_nms;                /* 0.7 */
+    float mask_thresh;            /* 0.5 */
+    int rpn_pre_topk;             /* 1000 (<= 1000) */
+    int rpn_post_topk;            /* 1000 (<= 1000) */
+    int dets_per_image;           /* 100  (<= 100) */
+    float pixel_mean[3];          /* BGR means */
+    int assoc_roi;                /* 10 */
+    int embed_dim;                /* 128 */
+    float assoc_scale;            /* roi_pool spatial scale = p2 width / frame width (rcnn_tracker.py:165) */
+} apse_config;
+
+/* Byte offsets of the per-forward results block (one D2H copy, apse_read_results). n = max_batch*dets_per_image. */
+typedef struct apse_results_layout {
+    size_t bytes;
+    int n_max, dets_per_image, embed_dim, max_batch;
+    size_t total;        /* int                 number of packed detections                           */
+    size_t offset;       /* int  [max_batch+1]  first packed index of each image                      */
+    size_t prop_count;   /* int  [max_batch]    RPN proposals kept per image                          */
+    size_t img;          /* int  [n]            image of each detection                               */
+    size_t cls;          /* int  [n]            predicted class                                       */
+    size_t roi;          /* int  [n]            proposal index the detection came from (-1 given box) */
+    size_t score;        /* f32  [n]                                                                  */
+    size_t box_resized;  /* f32  [n][4]         box in resized-image pixels                           */
+    size_t box;          /* f32  [n][4]         box in frame pixels (scaled + clipped)                */
+    size_t valid;        /* int  [n]            box non-empty after scaling (detector_postprocess)    */
+    size_t rect;         /* int  [n][4]         paste window x0,y0,x1,y1                              */
+    size_t mass;         /* int  [n]            mask pixel count                                      */
+    size_t centroid;     /* int  [n][2]         1-based floor centroid, -1 if empty                   */
+    size_t closest;      /* int  [n][dets_per_image][2]  closest mask pixel of det i to the centroid of
+                                                 the j-th detection of the same image, -1 if none     */
+    size_t embedding;    /* f32  [n][embed_dim] L2-normalised association embedding                   */
+} apse_results_layout;
+
+/* ---- lifetime ---- */
+int apse_create(const apse_config* cfg, apse_ctx** out);
+void apse_destroy(apse_ctx* ctx);
+const char* apse_last_error(apse_ctx* ctx);          /* ctx may be NULL: last creation error */
+const char* apse_version(void);
+
+/* ---- weights: replaces DetectionCheckpointer.load / load_state_dict (track_predictor.py:20-21,
+ * rcnn_tracker.py:55-57).  Names are detectron2 state_dict keys, plus "association.fc.weight|bias".
+ * Host f32 arrays in PyTorch layout.  apse_finalize_weights folds FrozenBN into the convolutions,
+ * re-lays the filters out for the implicit-GEMM kernels, uploads them and builds the launch plan. */
+int apse_set_weight(apse_ctx* ctx, const char* name, const float* host, const int64_t* shape, int ndim);
+int apse_finalize_weights(apse_ctx* ctx);
+
+/* Pillow resampling tables for frame->image (host int32; computed by the caller exactly as Pillow's
+ * precompute_coeffs/normalize_coeffs_8bpc do): bounds [out][2] = (first, count), coef [out][ksize]. */
+int apse_set_resize_tables(apse_ctx* ctx, const int* hbounds, const int* hcoef, int hksize, const int* vbounds,
+                           const int* vcoef, int vksize);
+
+/* ---- per-frame stages (all enqueue on `stream`) ---- */
+/* ResizeShortestEdge.apply_image (PIL bilinear) + preprocess_image: u8 BGR frames [B][frame_h][frame_w][3]
+ * -> internal normalised, /32-padded network input (track_predictor.py:48-49, track_rcnn.py:35). */
+int apse_preprocess_frames(apse_ctx* ctx, const uint8_t* frames_dev, int batch, void* stream);
+/* Same from already-resized f32 CHW images [B][3][image_h][image_w] (the reference's model input). */
+int apse_preprocess_images(apse_ctx* ctx, const float* images_dev, int batch, void* stream);
+/* ResNet-101 + FPN (track_rcnn.py:42). */
+int apse_backbone(apse_ctx* ctx, int batch, void* stream);
+/* RPN head + proposal selection (track_rcnn.py:46). */
+int apse_rpn(apse_ctx* ctx, int batch, void* stream);
+/* Box branch + FastRCNNOutputs.inference (track_rcnn.py:51) -> packed detection list. */
+int apse_box_head(apse_ctx* ctx, int batch, void* stream);
+/* roi_heads.forward_with_given_boxes (track_rcnn.py:52-54): host arrays, boxes in resized-image pixels,
+ * counts[batch] detections per image, concatenated.  Replaces apse_rpn + apse_box_head. */
+int apse_set_detections(apse_ctx* ctx, const float* boxes_host, const int* classes_host, const float* scores_host,
+                        const int* counts_host, int batch, void* stream);
+/* Mask branch + detector_postprocess/paste + centroids + closest-point table
+ * (track_rcnn.py:51,57; mask_utils.py:6-38). */
+int apse_mask_tail(apse_ctx* ctx, int batch, void* stream);
+/* roi_pool(p2) + AssociationHead (rcnn_tracker.py:156-189, association_head.py:16-27). */
+int apse_embed(apse_ctx* ctx, int batch, void* stream);
+/* backbone + rpn + box_head + mask_tail + embed. */
+int apse_forward(apse_ctx* ctx, int batch, void* stream);
+
+/* ---- results ---- */
+int apse_results_describe(apse_ctx* ctx, apse_results_layout* out);
+/* Copies the results block to host memory (layout->bytes) and synchronises the stream. */
+int apse_read_results(apse_ctx* ctx, void* host_dst, size_t bytes, void* stream);
+/* Copies detection i's mask window (rows rect.y0..y1, 64-bit words (x0>>6)..((x1+63)>>6)) to dst_dev. */
+int apse_copy_mask_window(apse_ctx* ctx, int det, int x0, int y0, int x1, int y1, uint64_t* dst_dev, void* stream);
+/* Named internal tensor -> caller buffer as NCHW f32 (p2..p6, res2..res5, stem): the feature dict
+ * TrackRCNN.inference returns (track_rcnn.py:57-58).  dims (B,C,H,W) via apse_feature_shape. */
+int apse_feature_shape(apse_ctx* ctx, const char* name, int* chw3);
+int apse_export_feature(apse_ctx* ctx, const char* name, float* dst_nchw_dev, int batch, void* stream);
+/* Debug/parity taps: copy a named intermediate (device, raw layout) to dst_dev; returns element count in *count. */
+int apse_debug_tensor(apse_ctx* ctx, const char* name, void* dst_dev, size_t max_bytes, size_t* bytes, void* stream);
+/* Algorithmic FLOPs of one forward for `batch` images with the given proposal/detection totals. */
+double apse_flops(apse_ctx* ctx, int batch, int proposals, int detections);
+
+/* ---- stage-level operators (stateless; used by the parity tests and by host-side helpers) ---- */
+typedef struct apse_conv_desc {
+    int B, H, W, Cin;       /* NHWC input, Cin a power of two >= 4 */
+    int Cout, KH, KW, stride, pad;
+    int relu;
+    int res_mode;           /* 0 none, 1 same-shape residual, 2 nearest-2x upsampled residual */
+    int cfg;                /* -1 auto, else tile config 0..3 */
+    int splitk;             /* 0 auto */
+} apse_conv_desc;
+size_t apse_conv_packed_elems(const apse_conv_desc* d);
+/* OIHW host filter (+ optional per-channel scale) -> packed host filter for apse_conv2d. */
+int apse_conv_pack_weight(const apse_conv_desc* d, const float* w_oihw, int cin_real, const float* scale, float* packed);
+int apse_conv2d(const apse_conv_desc* d, const float* x_dev, const float* w_packed_dev, const float* bias_dev,
+                const float* res_dev, float* y_dev, float* ws_dev, size_t ws_bytes, void* stream);
+int apse_maxpool3x3s2(const float* x_dev, float* y_dev, int B, int H, int W, int C, void* stream);
+/* ROIAlignV2 over 4 levels (NHWC, C = 256); rois [n][4], batch index roi/per_img, all rois live. */
+int apse_roi_align(const float* const* feats_dev, const int* hs, const int* ws, const float* rois_dev, int n, int per_img,
+                   int out_size, float* out_dev, void* stream);
+int apse_roi_pool(const float* feat_dev, int H, int W, const float* rois_dev, const int* roi_img_dev, int n, int out_size,
+                  float scale, float* out_dev, void* stream);
+/* Generic per-category NMS + ranking on [n] boxes (category = cat_dev[i] given as entry % cat_mod or / cat_div). */
+int apse_nms_rank(const float* boxes_dev, const float* scores_dev, const int* valid_dev, int n, int cat_div, int cat_mod,
+                  int ncat, float thr, int topk, float* out_boxes_dev, float* out_scores_dev, int* out_index_dev,
+                  int* out_count_dev, void* stream);
+/* mask_utils on a dense bool frame (uint8 0/1): centroid (1-based floor) and closest point to (px, py). */
+int apse_mask_centroid_dense(const uint8_t* mask_dev, int H, int W, int* out_xy_mass_host3, void* stream);
+int apse_mask_closest_dense(const uint8_t* mask_dev, int H, int W, float px, float py, int* out_xy_host2, void* stream);
+/* F.normalize(p=2) rows and the squared-distance matrix of rcnn_tracker.py:192-221. */
+int apse_l2_normalize(const float* x_dev, float* y_dev, int n, int D, void* stream);
+int apse_sqdist(const float* a_dev, const float* b_dev, int O, int N, int D, float* out_dev, void* stream);
+/* PIL resize + normalise as a stand-alone op (tables as in apse_set_resize_tables, device pointers). */
+int apse_resize_normalize(const uint8_t* frames_dev, uint8_t* tmp_dev, float* out_nhwc4_dev, uint8_t* resized_u8_dev,
+                          const int* hb_dev, const int* hc_dev, int hk, const int* vb_dev, const int* vc_dev, int vk, int B,
+                          int H, int W, int OH, int OW, int PH, int PW, const float* mean3_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

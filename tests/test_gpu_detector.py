@@ -1,0 +1,142 @@
+"""-m gpu: the whole per-frame path (HIP, through the reference-shaped engines) against the CPU oracle.
+
+Small configuration (one bottleneck per stage, 270x480 frames resized to 252x448) so the oracle
+finishes in seconds; the full R-101 / 4K configuration is covered by test_gpu_fullsize.py.
+Bars: indices / ids / classes exact; float tensors within the f32 tolerance stated per check.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BLOCKS = (1, 1, 1, 1)
+FRAME = (270, 480)
+
+
+def _cfg():
+    from apse_uav_amd.config import setup_cfg
+    cfg = setup_cfg()
+    cfg.INPUT.MIN_SIZE_TEST = 256
+    cfg.INPUT.MAX_SIZE_TEST = 448
+    return cfg
+
+
+def _log(logdir, name, obj):
+    with open(os.path.join(logdir, "detector_parity.log"), "a") as f:
+        f.write(name + " " + json.dumps(obj) + "\n")
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from PIL import Image
+    from apse_uav_amd.weights import synthetic_detector_state, synthetic_association_state
+    from apse_uav_amd.synthetic import SyntheticSequence
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from apse_uav_amd.utils import resample
+    from oracle.detector import DetectorOracle
+    from oracle import tracker as otr
+    sd = synthetic_detector_state(0, BLOCKS)
+    asd = synthetic_association_state(1)
+    seq = SyntheticSequence("dynamic", FRAME[0], FRAME[1])
+    cfg = _cfg()
+    tracker = RcnnTracker(cfg, FRAME, asd, detector_state=sd)
+    oracle = DetectorOracle(sd, dict(depth_blocks=BLOCKS, min_size=256, max_size=448))
+    ih, iw = resample.resize_shortest_edge(FRAME[0], FRAME[1], 256, 448)
+
+    def oracle_frame(frame):
+        img = np.asarray(Image.fromarray(frame).resize((iw, ih), Image.BILINEAR))
+        x = torch.as_tensor(img.astype("float32").transpose(2, 0, 1))
+        post = oracle.inference(x, FRAME[0], FRAME[1])
+        p2 = post["features"]["p2"]
+        rois = otr.features_rois(p2, post["boxes"], FRAME[1])
+        emb = otr.association_head(rois, asd["fc.weight"], asd["fc.bias"])
+        post["emb"] = emb
+        post["assoc_rois"] = rois
+        return post
+    return dict(sd=sd, asd=asd, seq=seq, cfg=cfg, tracker=tracker, oracle=oracle, oracle_frame=oracle_frame, ih=ih, iw=iw)
+
+
+def test_single_frame_stages(setup, logdir):
+    from oracle import mask_utils as omu
+    tr = setup["tracker"]
+    frame = setup["seq"].frame(0)
+    post = setup["oracle_frame"](frame)
+    pred, feats = tr.predictor(frame)
+    inst = pred["instances"]
+    model = tr.predictor.model
+    # ---- features (f32, rel. to max; accumulation-order noise through ~20 convolutions)
+    for k in ("p2", "p3", "p4", "p5", "p6"):
+        got = feats[k].cpu()
+        ref = post["features"][k]
+        d = float((got - ref).abs().max() / ref.abs().max())
+        _log(logdir, "feat/" + k, dict(rel=d, shape=list(got.shape)))
+        assert got.shape == ref.shape
+        assert d < 1e-4, (k, d)
+    # ---- proposals
+    res = model.last_results
+    P = int(res.prop_count[0])
+    props = model.debug_tensor("proposals").cpu().view(-1, 4)[:P]
+    ref_props = post["proposals"]["boxes"]
+    _log(logdir, "rpn", dict(P=P, ref_P=int(ref_props.shape[0])))
+    assert P == ref_props.shape[0]
+    dprop = float((props - ref_props).abs().max())
+    _log(logdir, "rpn_boxes", dict(max_abs=dprop))
+    assert dprop < 1e-2                       # pixels in the 252x448 image; same anchors selected in the same order
+    # ---- detections
+    n = len(inst)
+    _log(logdir, "dets", dict(n=n, ref_n=int(post["boxes"].shape[0]), scores=[float(s) for s in inst.scores[:8]],
+                              ref_scores=[float(s) for s in post["scores"][:8]]))
+    assert n == post["boxes"].shape[0]
+    assert torch.equal(inst.pred_classes, post["classes"])
+    assert float((inst.pred_boxes.tensor - post["boxes"]).abs().max()) < 2e-2      # frame pixels
+    assert float((inst.scores - post["scores"]).abs().max()) < 1e-5
+    # ---- masks: identical pixel sets up to threshold-edge pixels; centroids equal or off by one
+    bad_px = 0
+    for k in range(n):
+        m = inst.pred_masks[k]
+        win = m.window().cpu()
+        ref_win, ref_rect = post["mask_windows"][k], post["mask_rects"][k]
+        assert tuple(m.rect) == tuple(ref_rect)
+        bad_px += int((win != ref_win).sum())
+        rc = omu.window_centroid(ref_win, ref_rect)
+        if m.mass and not np.isnan(rc[0]):
+            assert abs(m.centroid[0] - rc[0]) <= 1 and abs(m.centroid[1] - rc[1]) <= 1
+    _log(logdir, "masks", dict(mismatched_pixels=bad_px, total=int(sum(int(m.mass) for m in inst.pred_masks))))
+    assert bad_px <= max(4, n)                 # >= 0.5 threshold on f32 bilinear values: a few edge pixels may flip
+    # ---- embeddings (unit vectors)
+    if n:
+        emb = torch.from_numpy(inst._record["embeddings"])
+        de = float((emb - post["emb"]).abs().max())
+        _log(logdir, "emb", dict(max_abs=de))
+        assert de < 1e-4
+
+
+def test_sequence_ids_and_csv(setup, logdir, tmp_path):
+    """Tracker over a short dynamic sequence: ids per frame and the CSV text must equal the oracle's."""
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from apse_uav_amd.utils import csv_log
+    from oracle import tracker as otr
+    tr = RcnnTracker(setup["cfg"], FRAME, setup["asd"], detector_state=setup["sd"])
+    otk = otr.TrackerOracle()
+    lines, olines = [], []
+    host = 1
+    for t in range(6):
+        frame = setup["seq"].frame(t)
+        rec = tr.next_frame(frame)
+        post = setup["oracle_frame"](frame)
+        det = dict(boxes=post["boxes"], scores=post["scores"], classes=post["classes"],
+                   masks=list(zip(post["mask_windows"], post["mask_rects"])), emb=post["emb"])
+        orec = otk.next_frame(det)
+        _log(logdir, "seq/%d" % t, dict(ids=list(rec.ids) if len(rec) else [], ref_ids=orec["ids"]))
+        assert (list(rec.ids) if len(rec) else []) == orec["ids"]
+        line, hi = tr.log_line(rec, host, t)
+        oline, ohi = otr.log_oneline(orec, host, t)
+        lines.append(line)
+        olines.append(oline)
+    same = sum(1 for a, b in zip(lines, olines) if a == b)
+    _log(logdir, "seq/csv", dict(same_lines=same, n=len(lines), sample=lines[0][:120], ref=olines[0][:120]))
+    assert same >= len(lines) - 1              # integer cells; a threshold-edge pixel may move one centroid by 1

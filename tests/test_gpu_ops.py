@@ -1,0 +1,272 @@
+"""-m gpu: stage-level parity of the HIP operators against the CPU oracle / torch CPU f32.
+
+Every case feeds identical seeded inputs to both sides.  Float outputs: tolerance written
+per test (f32 accumulation order differs; the MFMA path is an exact-f32 fma chain).
+Integer / index outputs: exact.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _log(logdir, name, obj):
+    with open(os.path.join(logdir, "ops_parity.log"), "a") as f:
+        f.write(name + " " + json.dumps(obj) + "\n")
+
+
+CONV_CASES = [
+    # name, B, Cin, H, W, Cout, K, stride, pad, relu, res_mode, cfg, splitk
+    ("c1x1_128", 1, 64, 24, 40, 256, 1, 1, 0, True, 0, 0, 0),
+    ("c1x1_64t", 1, 256, 20, 28, 64, 1, 1, 0, True, 0, 1, 0),
+    ("c3x3_auto", 1, 64, 30, 44, 64, 3, 1, 1, True, 0, -1, 0),
+    ("c3x3_128", 2, 128, 17, 23, 128, 3, 1, 1, False, 1, 0, 0),
+    ("c1x1_s2", 1, 256, 24, 36, 128, 1, 2, 0, True, 0, -1, 0),
+    ("c1x1_n32", 1, 256, 19, 21, 15, 1, 1, 0, False, 0, 2, 0),
+    ("c3x3_n64", 1, 64, 26, 38, 64, 3, 1, 1, True, 0, 3, 0),
+    ("stem7x7", 1, 3, 64, 96, 64, 7, 2, 3, True, 0, -1, 0),
+    ("splitk", 1, 512, 12, 14, 128, 3, 1, 1, True, 1, 1, 5),
+    ("upres", 1, 128, 16, 24, 256, 1, 1, 0, False, 2, -1, 0),
+    ("fc7x7", 37, 256, 7, 7, 1024, 7, 1, 0, True, 0, -1, 0),
+    ("fc_small_m", 3, 256, 10, 10, 128, 10, 1, 0, False, 0, -1, 0),
+    ("big_k", 1, 2048, 6, 10, 512, 1, 1, 0, True, 0, -1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_parity(case, logdir):
+    from hip_helpers import hip_conv2d, err_stats
+    name, B, Cin, H, W, Cout, K, stride, pad, relu, res_mode, cfg, splitk = case
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    res = None
+    if res_mode == 1:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res
+    elif res_mode == 2:
+        res = torch.randn(B, Cout, ref.shape[2] // 2, ref.shape[3] // 2, generator=g)
+        ref = ref + F.interpolate(res, scale_factor=2, mode="nearest")
+    if relu:
+        ref = F.relu(ref)
+    out = hip_conv2d(x, w, b, stride, pad, relu, res, res_mode, cfg, splitk)
+    st = err_stats(out, ref)
+    _log(logdir, "conv/" + name, st)
+    assert st["nan"] == 0
+    assert st["rel_to_max"] < 2e-5, st          # f32 tolerance: accumulation-order noise only
+
+
+def test_maxpool(logdir):
+    from apse_uav_amd import _lib
+    from hip_helpers import to_nhwc
+    x = torch.randn(2, 64, 37, 50)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    xd = to_nhwc(x).cuda()
+    y = torch.empty((2, ref.shape[2], ref.shape[3], 64), device="cuda")
+    assert _lib.load().apse_maxpool3x3s2(_lib.ptr(xd), _lib.ptr(y), 2, 37, 50, 64, _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu().permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("hw", [(2160, 3840), (540, 960), (333, 516)])
+def test_pil_resize_bit_exact(hw, logdir):
+    """HIP two-pass integer resize + normalise vs Pillow itself (the reference's resampler)."""
+    from PIL import Image
+    from apse_uav_amd import _lib
+    from apse_uav_amd.utils import resample
+    H, W = hw
+    rng = np.random.default_rng(H)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    oh, ow = resample.resize_shortest_edge(H, W)
+    if H == 333:
+        oh, ow = 121, 203
+    ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+    hb, hc, hk = resample.precompute_coeffs(W, ow)
+    vb, vc, vk = resample.precompute_coeffs(H, oh)
+    dev = "cuda"
+    ph, pw = (oh + 31) // 32 * 32, (ow + 31) // 32 * 32
+    src = torch.from_numpy(img).to(dev)
+    tmp = torch.empty((H, ow, 3), dtype=torch.uint8, device=dev)
+    out = torch.zeros((1, ph, pw, 4), device=dev)
+    rs = torch.empty((oh, ow, 3), dtype=torch.uint8, device=dev)
+    t = [torch.from_numpy(a).to(dev) for a in (hb, hc, vb, vc)]
+    mean = (C.c_float * 3)(103.530, 116.280, 123.675)
+    rc = _lib.load().apse_resize_normalize(_lib.ptr(src), _lib.ptr(tmp), _lib.ptr(out), _lib.ptr(rs), _lib.ptr(t[0]),
+                                           _lib.ptr(t[1]), hk, _lib.ptr(t[2]), _lib.ptr(t[3]), vk, 1, H, W, oh, ow, ph, pw,
+                                           C.byref(mean), _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = rs.cpu().numpy()
+    nd = int((got != ref).sum())
+    _log(logdir, "resize/%dx%d" % hw, dict(mismatch=nd))
+    assert nd == 0
+    exp = torch.from_numpy(ref.astype(np.float32)) - torch.tensor([103.530, 116.280, 123.675])
+    o = out.cpu()[0]
+    assert torch.equal(o[:oh, :ow, :3], exp)
+    assert float(o[oh:].abs().sum()) == 0.0 and float(o[:, ow:].abs().sum()) == 0.0 and float(o[..., 3].abs().sum()) == 0.0
+
+
+def test_roi_align_parity(logdir):
+    from oracle import ops
+    from apse_uav_amd import _lib
+    from hip_helpers import to_nhwc, err_stats
+    g = torch.Generator().manual_seed(3)
+    sizes = [(48, 84), (24, 42), (12, 21), (6, 11)]
+    feats = [torch.randn(1, 256, h, w, generator=g) for h, w in sizes]
+    n = 300
+    cx = torch.rand(n, generator=g) * 330
+    cy = torch.rand(n, generator=g) * 190
+    bw = torch.rand(n, generator=g) ** 2 * 300 + 1
+    bh = torch.rand(n, generator=g) ** 2 * 180 + 1
+    boxes = torch.stack([(cx - bw / 2).clamp(0, 336), (cy - bh / 2).clamp(0, 192), (cx + bw / 2).clamp(0, 336),
+                         (cy + bh / 2).clamp(0, 192)], dim=1)
+    boxes[0] = torch.tensor([0., 0., 336., 192.])
+    boxes[1] = torch.tensor([10., 10., 10.5, 10.2])
+    for R in (7, 14):
+        ref = ops.roi_pooler([f[0] for f in feats], boxes, R)
+        fd = [to_nhwc(f).cuda() for f in feats]
+        ptrs = (C.c_void_p * 4)(*[f.data_ptr() for f in fd])
+        hs = (C.c_int * 4)(*[s[0] for s in sizes])
+        ws = (C.c_int * 4)(*[s[1] for s in sizes])
+        out = torch.full((n, R, R, 256), float("nan"), device="cuda")
+        bd = boxes.cuda().contiguous()
+        assert _lib.load().apse_roi_align(ptrs, hs, ws, _lib.ptr(bd), n, n, R, _lib.ptr(out), _lib.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        st = err_stats(out.cpu().permute(0, 3, 1, 2), ref)
+        _log(logdir, "roi_align/%d" % R, st)
+        assert st["nan"] == 0 and st["max_abs"] < 1e-4, st       # f32, bilinear weights: order-of-sum noise
+
+
+def test_roi_pool_parity(logdir):
+    from oracle import ops
+    from apse_uav_amd import _lib
+    from hip_helpers import to_nhwc
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(1, 256, 48, 84, generator=g)
+    n = 40
+    x1 = torch.rand(n, generator=g) * 800
+    y1 = torch.rand(n, generator=g) * 500
+    boxes = torch.stack([x1, y1, x1 + torch.rand(n, generator=g) * 300, y1 + torch.rand(n, generator=g) * 150], dim=1)
+    boxes[0] = torch.tensor([0., 0., 960., 540.])
+    boxes[1] = torch.tensor([955., 530., 960., 540.])
+    scale = 84 / 960.0
+    rois = torch.cat([torch.zeros(n, 1), boxes], dim=1)
+    ref = ops.roi_pool(feat, rois, 10, scale)
+    out = torch.full((n, 10, 10, 256), float("nan"), device="cuda")
+    fd = to_nhwc(feat).cuda()
+    img = torch.zeros(n, dtype=torch.int32, device="cuda")
+    bd = boxes.cuda().contiguous()
+    assert _lib.load().apse_roi_pool(_lib.ptr(fd), 48, 84, _lib.ptr(bd), _lib.ptr(img), n, 10, float(scale), _lib.ptr(out),
+                                     _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu().permute(0, 3, 1, 2), ref)            # max of the same cells: bit-exact
+
+
+@pytest.mark.parametrize("seed,n,ncat,thr,topk", [(0, 5000, 5, 0.7, 1000), (1, 4000, 4, 0.5, 100), (2, 37, 4, 0.5, 100),
+                                                   (3, 1, 1, 0.5, 10)])
+def test_nms_rank_exact(seed, n, ncat, thr, topk, logdir):
+    """Per-category NMS + ranking: kept indices must equal torchvision-style batched_nms exactly."""
+    from oracle import ops
+    from apse_uav_amd import _lib
+    g = torch.Generator().manual_seed(seed)
+    cx = torch.rand(n, generator=g) * 1300
+    cy = torch.rand(n, generator=g) * 700
+    w = torch.rand(n, generator=g) * 200 + 2
+    h = torch.rand(n, generator=g) * 200 + 2
+    boxes = torch.stack([(cx - w / 2).clamp(0, 1333), (cy - h / 2).clamp(0, 750), (cx + w / 2).clamp(0, 1333),
+                         (cy + h / 2).clamp(0, 750)], dim=1)
+    scores = torch.rand(n, generator=g)
+    scores[::7] = scores[3]                      # exact ties: exercises the index tie-break
+    valid = (torch.rand(n, generator=g) > 0.1)
+    if ncat == 5:
+        per = n // ncat
+        cat = torch.arange(n) // per
+        cat_div, cat_mod = per, 0
+    else:
+        cat = torch.arange(n) % ncat
+        cat_div, cat_mod = 0, ncat
+    vi = torch.nonzero(valid).squeeze(1)
+    kept = ops.batched_nms(boxes[vi], scores[vi], cat[vi], thr)[:topk]
+    ref_idx = vi[torch.from_numpy(kept)].numpy()
+    dev = "cuda"
+    ob = torch.empty((topk, 4), device=dev)
+    os_ = torch.empty((topk,), device=dev)
+    oi = torch.empty((topk,), dtype=torch.int32, device=dev)
+    oc = torch.zeros((1,), dtype=torch.int32, device=dev)
+    rc = _lib.load().apse_nms_rank(_lib.ptr(boxes.cuda().contiguous()), _lib.ptr(scores.cuda()),
+                                   _lib.ptr(valid.to(torch.int32).cuda()), n, cat_div, cat_mod, ncat, thr, topk, _lib.ptr(ob),
+                                   _lib.ptr(os_), _lib.ptr(oi), _lib.ptr(oc), _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    cnt = int(oc.cpu()[0])
+    got = oi.cpu().numpy()[:cnt]
+    _log(logdir, "nms/%d" % seed, dict(ref=len(ref_idx), got=cnt, equal=bool(len(ref_idx) == cnt and (got == ref_idx).all())))
+    assert cnt == len(ref_idx)
+    assert (got == ref_idx).all()
+    assert torch.equal(ob.cpu()[:cnt], boxes[torch.from_numpy(ref_idx.astype(np.int64))])
+
+
+def test_mask_utils_golden(golden_dir, logdir):
+    """get_mask_centroid / compute_closest_point on the GPU vs vectors from the reference's own functions."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden import make_mask
+    from apse_uav_amd.utils import mask_utils
+    with open(os.path.join(golden_dir, "mask_utils_golden.json")) as f:
+        gold = json.load(f)
+    H, W = gold["height"], gold["width"]
+    for c in gold["cases"]:
+        m = torch.from_numpy(make_mask(H, W, c["spec"])).cuda()
+        cen = mask_utils.get_mask_centroid(m)
+        clo = mask_utils.compute_closest_point(m, c["point"])
+        _log(logdir, "mask/" + c["name"], dict(cen=cen, ref_cen=c["centroid"], clo=clo, ref_clo=c["closest"]))
+        assert list(clo) == c["closest"], c["name"]
+        if c["name"] in ("tie_sym", "far_f32"):
+            # exact mean is an integer; the reference's f32 sum lands just below it (order-dependent)
+            assert abs(cen[0] - c["centroid"][0]) <= 1 and abs(cen[1] - c["centroid"][1]) <= 1
+        else:
+            assert list(cen) == c["centroid"], c["name"]
+
+
+def test_association_head_golden(golden_dir, logdir):
+    from apse_uav_amd.networks.association_head import AssociationHead
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden import formula_tensor
+    g = np.load(os.path.join(golden_dir, "association_head_golden.npz"))
+    head = AssociationHead(10, 256)
+    head.load_state_dict({"fc.weight": formula_tensor((128, 25600), 131, 71, 257, 8192.0),
+                          "fc.bias": formula_tensor((128,), 17, 5, 61, 64.0)})
+    x = formula_tensor((3, 256, 10, 10), 37, 11, 509, 97.0)
+    x[1] = torch.relu(x[1])
+    x[2] = 0.0
+    y = head(x.cuda()).cpu().numpy()
+    d = float(np.abs(y - g["full_out"]).max())
+    small = AssociationHead(10, 8)
+    small.load_state_dict({"fc.weight": torch.from_numpy(g["small_w"]), "fc.bias": torch.from_numpy(g["small_b"])})
+    ys = small(torch.from_numpy(g["small_x"]).cuda()).cpu().numpy()
+    d2 = float(np.abs(ys - g["small_out"]).max())
+    _log(logdir, "assoc_head", dict(full=d, small=d2))
+    assert d < 2e-6 and d2 < 2e-6            # unit vectors, f32: accumulation-order noise over K = 25600
+
+
+def test_sqdist_and_normalize(logdir):
+    from oracle import tracker as otr
+    from apse_uav_amd import _lib
+    g = torch.Generator().manual_seed(9)
+    a = torch.nn.functional.normalize(torch.randn(7, 128, generator=g), dim=1)
+    b = torch.nn.functional.normalize(torch.randn(5, 128, generator=g), dim=1)
+    ref = otr.distance_matrix([a[i] for i in range(7)], b)
+    out = torch.empty((7, 5), device="cuda")
+    assert _lib.load().apse_sqdist(_lib.ptr(a.cuda()), _lib.ptr(b.cuda()), 7, 5, 128, _lib.ptr(out), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert float((out.cpu() - ref).abs().max()) < 1e-6
