@@ -81,6 +81,8 @@ def load():
         "apse_export_feature": ([vp, C.c_char_p, vp, i, vp], i),
         "apse_debug_tensor": ([vp, C.c_char_p, vp, sz, C.POINTER(sz), vp], i),
         "apse_flops": ([vp, i, i, i], C.c_double),
+        "apse_profile": ([vp, i], i),
+        "apse_profile_read": ([vp, C.POINTER(C.c_double * 24), i], i),
         "apse_conv_packed_elems": ([C.POINTER(ConvDesc)], sz),
         "apse_conv_pack_weight": ([C.POINTER(ConvDesc), vp, i, vp, vp], i),
         "apse_conv2d": ([C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, sz, vp], i),
@@ -106,7 +108,7 @@ EXPORTS = ["apse_create", "apse_destroy", "apse_last_error", "apse_version", "ap
            "apse_set_resize_tables", "apse_preprocess_frames", "apse_preprocess_images", "apse_backbone", "apse_rpn",
            "apse_box_head", "apse_set_detections", "apse_mask_tail", "apse_embed", "apse_forward", "apse_results_describe",
            "apse_read_results", "apse_copy_mask_window", "apse_feature_shape", "apse_export_feature", "apse_debug_tensor",
-           "apse_flops", "apse_conv_packed_elems", "apse_conv_pack_weight", "apse_conv2d", "apse_maxpool3x3s2",
+           "apse_flops", "apse_profile", "apse_profile_read", "apse_conv_packed_elems", "apse_conv_pack_weight", "apse_conv2d", "apse_maxpool3x3s2",
            "apse_roi_align", "apse_roi_pool", "apse_nms_rank", "apse_mask_centroid_dense", "apse_mask_closest_dense",
            "apse_l2_normalize", "apse_sqdist", "apse_resize_normalize"]
 

@@ -97,6 +97,10 @@ struct apse_ctx {
     // mask tail
     uint64_t* bits = nullptr; unsigned long long* sums = nullptr; int wpr = 0;
     float* emb_raw = nullptr;
+    // per-kernel profiling with HIP events on the caller's stream (bench.py roofline)
+    bool prof_on = false; std::vector<hipEvent_t> ev_pool; int ev_used = 0;
+    struct Pending { int cfg; double flops_per_item; int count_kind; int b_mult; int batch; int e0, e1; };
+    std::vector<Pending> pending; double prof[8][3] = {{0}};
     // stateless-op scratch
     uint64_t* op_bits = nullptr; unsigned long long* op_sums = nullptr; size_t op_bits_words = 0;
 };
@@ -290,7 +294,16 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
             p.m_count = nullptr; p.m_per_item = p.OH * p.OW;
             if (st.c.count_kind == 2) p.m_count = total_dev;
             else if (st.c.count_kind == 1 && batch == 1) p.m_count = propcnt_dev;
+            int e0 = -1;
+            if (c->prof_on && c->ev_used + 2 <= (int)c->ev_pool.size()) {
+                e0 = c->ev_used; c->ev_used += 2;
+                hipEventRecord(c->ev_pool[e0], s);
+            }
             rc = apse_launch_conv(p, st.c.cfg, s);
+            if (e0 >= 0) {
+                hipEventRecord(c->ev_pool[e0 + 1], s);
+                c->pending.push_back({st.c.cfg, st.c.flops_per_item, st.c.count_kind, st.c.b_mult, batch, e0, e0 + 1});
+            }
         } else if (st.kind == S_MAXPOOL) {
             rc = apse_k_maxpool3x3s2(st.x, st.y, batch, st.H, st.W, st.C, s);
         } else {
@@ -795,6 +808,40 @@ int apse_read_results(apse_ctx* c, void* host_dst, size_t bytes, void* stream) {
     if (bytes < c->lay.bytes) return fail(c, APSE_E_INVALID, "results buffer too small");
     HIPCHK(c, hipMemcpyAsync(host_dst, c->res, c->lay.bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+    if (c->prof_on) {
+        const uint8_t* h = reinterpret_cast<const uint8_t*>(host_dst);
+        const int total = *reinterpret_cast<const int*>(h + c->lay.total);
+        const int* pc = reinterpret_cast<const int*>(h + c->lay.prop_count);
+        for (auto& q : c->pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev_pool[q.e0], c->ev_pool[q.e1]) != hipSuccess) continue;
+            double items = q.batch;
+            if (q.count_kind == 1) { items = 0; for (int b = 0; b < q.batch; ++b) items += pc[b]; }
+            else if (q.count_kind == 2) items = total;
+            c->prof[q.cfg][0] += ms; c->prof[q.cfg][1] += q.flops_per_item * items; c->prof[q.cfg][2] += 1;
+        }
+        c->pending.clear();
+        c->ev_used = 0;
+    }
+    return APSE_OK;
+}
+
+int apse_profile(apse_ctx* c, int enable) {
+    if (!c) return APSE_E_INVALID;
+    if (enable && c->ev_pool.empty()) {
+        c->ev_pool.resize(1024);
+        for (auto& e : c->ev_pool) if (hipEventCreate(&e) != hipSuccess) return fail(c, APSE_E_HIP, "hipEventCreate");
+    }
+    c->prof_on = enable != 0;
+    c->pending.clear();
+    c->ev_used = 0;
+    return APSE_OK;
+}
+
+int apse_profile_read(apse_ctx* c, double* out24, int reset) {
+    if (!c || !out24) return APSE_E_INVALID;
+    memcpy(out24, c->prof, sizeof(c->prof));
+    if (reset) memset(c->prof, 0, sizeof(c->prof));
     return APSE_OK;
 }
 

@@ -1,0 +1,87 @@
+"""Frame sharding across GPUs and the single gather of per-frame records.
+
+The reference is single-process.  Per-frame GPU work (detector, masks, centroids, closest-point
+table, embeddings) is a pure function of one frame, so frames shard embarrassingly across ranks;
+only the id assignment (Hungarian + track store, /root/reference/dcnn/engines/rcnn_tracker.py:122-147)
+is sequential.  Each rank therefore emits a fixed-layout record per frame and rank 0 receives all of
+them with ONE collective at sequence end (``torch.distributed`` gather: RCCL over xGMI with the
+"nccl" backend on GPUs, gloo in the CPU tests), then replays the association in frame order.
+"""
+import numpy as np
+import torch
+
+_FIELDS = (("boxes", np.float32, 4), ("scores", np.float32, 1), ("classes", np.int64, 1), ("centroids", np.int32, 2),
+           ("mass", np.int32, 1), ("rects", np.int32, 4))
+
+
+def shard_frames(n_frames, rank, world):
+    """Contiguous frame range [lo, hi) of this rank."""
+    per = (n_frames + world - 1) // world
+    lo = min(rank * per, n_frames)
+    return lo, min(lo + per, n_frames)
+
+
+def pack_record(rec, kd, edim):
+    """Record -> flat f32 vector of fixed length (so one tensor gather moves every frame)."""
+    n = len(rec["scores"])
+    out = np.zeros(record_len(kd, edim), np.float32)
+    out[0] = n
+    o = 1
+    for name, _, width in _FIELDS:
+        a = np.asarray(rec[name]).reshape(n, width).astype(np.float32)    # all values < 2^24: exact in f32
+        out[o:o + n * width] = a.reshape(-1)
+        o += kd * width
+    cl = np.asarray(rec["closest"], np.float32).reshape(n, n, 2)
+    blk = np.zeros((kd, kd, 2), np.float32)
+    blk[:n, :n] = cl
+    out[o:o + kd * kd * 2] = blk.reshape(-1)
+    o += kd * kd * 2
+    emb = np.zeros((kd, edim), np.float32)
+    emb[:n] = rec["embeddings"]
+    out[o:o + kd * edim] = emb.reshape(-1)
+    return out
+
+
+def record_len(kd, edim):
+    return 1 + kd * sum(w for _, _, w in _FIELDS) + kd * kd * 2 + kd * edim
+
+
+def unpack_record(vec, kd, edim):
+    n = int(vec[0])
+    rec = {}
+    o = 1
+    for name, dt, width in _FIELDS:
+        a = vec[o:o + n * width].reshape(n, width).astype(dt)
+        rec[name] = a[:, 0] if width == 1 else a
+        o += kd * width
+    rec["closest"] = vec[o:o + kd * kd * 2].reshape(kd, kd, 2)[:n, :n].astype(np.int32)
+    o += kd * kd * 2
+    rec["embeddings"] = vec[o:o + kd * edim].reshape(kd, edim)[:n].astype(np.float32).copy()
+    rec["packed_index"] = np.arange(n)
+    return rec
+
+
+def gather_records(records, rank, world, device, kd=100, edim=128):
+    """All ranks call this once; rank 0 gets the records of every rank in rank order (frame order for
+    contiguous shards), the others get None.  Ranks may hold different numbers of frames."""
+    import torch.distributed as dist
+    L = record_len(kd, edim)
+    cnt = torch.tensor([len(records)], device=device, dtype=torch.int64)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    mx = int(max(int(c.item()) for c in cnts))
+    buf = torch.zeros((mx, L), dtype=torch.float32)
+    for i, r in enumerate(records):
+        buf[i] = torch.from_numpy(pack_record(r, kd, edim))
+    buf = buf.to(device)
+    if rank == 0:
+        outs = [torch.zeros_like(buf) for _ in range(world)]
+        dist.gather(buf, outs, dst=0)
+        res = []
+        for r in range(world):
+            h = outs[r].cpu().numpy()
+            for i in range(int(cnts[r].item())):
+                res.append(unpack_record(h[i], kd, edim))
+        return res
+    dist.gather(buf, None, dst=0)
+    return None

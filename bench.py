@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the dcnn hot path on MI355X: 4K UAV frames/s (whole job) + p50 per-frame latency.
+
+Workload (BASELINE.json configs[1]): synthetic "static" 3840x2160 sequence, batch 1, f32, Mask R-CNN
+R-101-FPN with seeded synthetic weights (no weights or video ship with the reference), frames resident in
+HBM before the timed region.  One step = one batch through the whole per-frame path: PIL-exact resize +
+normalise, backbone + FPN, RPN + proposal selection, box head + NMS, mask head + paste + centroid/closest
+points, roi_pool + association embedding, D2H of the results block, host association (Hungarian) and the
+CSV line.  N > 1: one process per GPU, frames sharded by rank (weak scaling), a single gather of the
+per-frame records to rank 0 after the last step, which then runs the sequential id assignment.
+
+Prints ONE JSON line (see the contract in the task description), plus
+  roofline     : the dominant kernel's algorithmic FLOP/s measured with HIP events inside the timed region
+  cpu_baseline : the CPU oracle (oracle/, PyTorch CPU f32) timed on this host, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG_NAMES = ["conv_igemm_f32<128x128>", "conv_igemm_f32<64x64>", "conv_igemm_f32<128x32>", "conv_igemm_f32<128x64>"]
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--frame", type=str, default="2160x3840")
+    ap.add_argument("--blocks", type=str, default="3,4,23,3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--bg-bias", type=float, default=1.2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from apse_uav_amd import _lib
+    from apse_uav_amd.config import setup_cfg
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from apse_uav_amd.sharding import gather_records
+    from apse_uav_amd.synthetic import SyntheticSequence
+    from apse_uav_amd.weights import synthetic_association_state, synthetic_detector_state
+
+    H, W = [int(v) for v in args.frame.split("x")]
+    blocks = tuple(int(v) for v in args.blocks.split(","))
+    B = args.batch
+    sd = synthetic_detector_state(0, blocks, bg_bias=args.bg_bias)
+    asd = synthetic_association_state(1)
+    cfg = setup_cfg(device="cuda:%d" % local_rank)
+    cfg.APSE.MAX_BATCH = B
+    tracker = RcnnTracker(cfg, (H, W), asd, detector_state=sd)
+    model = tracker.predictor.model
+
+    # frames of this rank's shard, resident in HBM before timing (8 distinct frames, cycled)
+    seq = SyntheticSequence("static", H, W)
+    nres = 8
+    host_frames = [seq.frame(rank * 1000 + i) for i in range(nres)]
+    frames = torch.stack([torch.from_numpy(f) for f in host_frames]).to(dev)
+
+    lib = _lib.load()
+    records = []
+
+    def step(i, timed):
+        idx = [(i * B + k) % nres for k in range(B)]
+        batch = frames[idx] if B > 1 else frames[idx[0]:idx[0] + 1]
+        model.preprocess_frames(batch)
+        model.run(B)
+        res = model.read(B)                       # D2H of the results block + stream sync
+        for b in range(B):
+            rec = res.record(b)
+            if world == 1:
+                objs = tracker.next_record(rec)
+                tracker.log_line(objs, 1, i * B + b)
+            elif timed:
+                records.append(rec)
+        return res
+
+    for i in range(args.warmup):
+        res = step(i, False)
+    torch.cuda.synchronize()
+    _lib.check(lib.apse_profile(model._ctx, 1), model._ctx, "apse_profile")
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lat = []
+    P_sum = N_sum = 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ts = time.perf_counter()
+        res = step(args.warmup + i, True)
+        lat.append(time.perf_counter() - ts)
+        P_sum += int(res.prop_count[:B].sum())
+        N_sum += res.total
+    if dist is not None:
+        allrec = gather_records(records, rank, world, dev)      # the single exchange step (RCCL over xGMI)
+        if rank == 0:
+            for rec in allrec:
+                objs = tracker.next_record(rec)
+                tracker.log_line(objs, 1, tracker.frame_count - 1)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    import ctypes as C
+    prof = (C.c_double * 24)()
+    lib.apse_profile_read(model._ctx, C.byref(prof), 1)
+    lib.apse_profile(model._ctx, 0)
+    prof = np.array(list(prof)).reshape(8, 3)
+
+    if rank == 0:
+        frames_total = args.steps * B * world
+        fps = frames_total / elapsed
+        dom = int(np.argmax(prof[:, 0]))
+        ms, fl, nl = prof[dom]
+        achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        total_conv_ms = float(prof[:, 0].sum())
+        flops_frame = model.flops(1, P_sum / max(args.steps * B, 1), N_sum / max(args.steps * B, 1))
+        out = {
+            "metric": "4K UAV frames/sec (whole node)", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "p50_ms_per_frame": round(1000.0 * float(np.median(lat)) / B, 3),
+            "config": {"workload": "static synthetic 3840x2160 sequence, batch=%d f32, Mask R-CNN R-%s-FPN, %d GPU(s), "
+                                   "frames sharded per rank" % (B, "101" if blocks == (3, 4, 23, 3) else str(blocks), world),
+                       "frame": "%dx%d" % (W, H), "batch_per_gpu": B, "proposals_per_frame": P_sum / max(args.steps * B, 1),
+                       "detections_per_frame": N_sum / max(args.steps * B, 1),
+                       "gflop_per_frame_algorithmic": round(flops_frame / 1e9, 2)},
+            "roofline": {"bound": "mfma", "kernel": CFG_NAMES[dom], "achieved": round(achieved, 3),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": None, "avg_launch_ms": round(ms / max(nl, 1), 5), "launches": int(nl),
+                         "all_kernels": {CFG_NAMES[k]: {"ms": round(float(prof[k, 0]), 3),
+                                                        "tflops": round(float(prof[k, 1] / max(prof[k, 0], 1e-9) / 1e9), 3),
+                                                        "launches": int(prof[k, 2])} for k in range(4)},
+                         "conv_ms_per_frame": round(total_conv_ms / max(args.steps * B, 1), 3),
+                         "whole_path_tflops": round(flops_frame * fps / world / 1e12, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, asd, host_frames, blocks, H, W, args.cpu_frames)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd, asd, host_frames, blocks, H, W, nframes):
+    """The CPU oracle (a port: the reference's own CPU path cannot run, detectron2 is absent) on the same
+    frames and weights: PIL resize + detector + roi_pool/embedding + tracker association + CSV line."""
+    from PIL import Image
+    from oracle import tracker as otr
+    from oracle.detector import DetectorOracle, resize_shape
+    ncores = torch.get_num_threads()
+    oracle = DetectorOracle(sd, dict(depth_blocks=blocks))
+    ih, iw = resize_shape(H, W)
+    otk = otr.TrackerOracle()
+
+    def one(fr, t):
+        img = np.asarray(Image.fromarray(fr).resize((iw, ih), Image.BILINEAR))
+        post = oracle.inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), H, W)
+        rois = otr.features_rois(post["features"]["p2"], post["boxes"], W)
+        emb = otr.association_head(rois, asd["fc.weight"], asd["fc.bias"])
+        rec = otk.next_frame(dict(boxes=post["boxes"], scores=post["scores"], classes=post["classes"],
+                                  masks=list(zip(post["mask_windows"], post["mask_rects"])), emb=emb))
+        otr.log_oneline(rec, 1, t)
+    with torch.no_grad():
+        one(host_frames[0], 0)
+        t0 = time.perf_counter()
+        for t in range(nframes):
+            one(host_frames[(t + 1) % len(host_frames)], t + 1)
+        dt = time.perf_counter() - t0
+    return {"value": round(nframes / dt, 4), "unit": "frames/s", "cores": ncores, "kind": "port",
+            "sample": "%d frames of the same synthetic 3840x2160 sequence after 1 warm-up, PyTorch-CPU f32 oracle "
+                      "(torch threads = %d)" % (nframes, ncores)}
+
+
+if __name__ == "__main__":
+    main()

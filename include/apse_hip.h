@@ -133,6 +133,12 @@ int apse_debug_tensor(apse_ctx* ctx, const char* name, void* dst_dev, size_t max
 /* Algorithmic FLOPs of one forward for `batch` images with the given proposal/detection totals. */
 double apse_flops(apse_ctx* ctx, int batch, int proposals, int detections);
 
+/* Per-kernel timing with HIP events on the caller's stream (one pair per convolution launch, collected at
+ * apse_read_results).  out24 = [8 tile configs][3] = {sum ms, sum algorithmic FLOPs, launches}; configs
+ * 0..3 = 128x128, 64x64, 128x32, 128x64 implicit-GEMM tiles (a split-K launch includes its reduce pass). */
+int apse_profile(apse_ctx* ctx, int enable);
+int apse_profile_read(apse_ctx* ctx, double* out24, int reset);
+
 /* ---- stage-level operators (stateless; used by the parity tests and by host-side helpers) ---- */
 typedef struct apse_conv_desc {
     int B, H, W, Cin;       /* NHWC input, Cin a power of two >= 4 */
