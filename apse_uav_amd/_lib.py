@@ -80,7 +80,7 @@ def load():
         "apse_feature_shape": ([vp, C.c_char_p, C.POINTER(C.c_int * 3)], i),
         "apse_export_feature": ([vp, C.c_char_p, vp, i, vp], i),
         "apse_debug_tensor": ([vp, C.c_char_p, vp, sz, C.POINTER(sz), vp], i),
-        "apse_flops": ([vp, i, i, i], C.c_double),
+        "apse_flops": ([vp, i, C.c_double, C.c_double], C.c_double),
         "apse_profile": ([vp, i], i),
         "apse_profile_read": ([vp, C.POINTER(C.c_double * 24), i], i),
         "apse_conv_packed_elems": ([C.POINTER(ConvDesc)], sz),

@@ -137,27 +137,33 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
             if (s + 1 < s_end) load_step(s + 1);
             const float* Ab = As + buf * BM * 32;
             const float* Bb = Bs + buf * BN * 32;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4 af[TM], bf[TN];
+            // fragments are double-buffered in registers: the ds_read_b128s of chunk c+1 are issued
+            // before the MFMAs of chunk c, so LDS latency hides behind the matrix pipe.
+            f32x4 af[2][TM], bf[2][TN];
+            auto load_frags = [&](int c, int fb) {
                 const int ls = 2 * c + fh;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int row = (wm * TM + i) * 32 + fr;
-                    af[i] = *reinterpret_cast<const f32x4*>(Ab + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
+                    af[fb][i] = *reinterpret_cast<const f32x4*>(Ab + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int row = (wn * TN + j) * 32 + fr;
-                    bf[j] = *reinterpret_cast<const f32x4*>(Bb + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
+                    bf[fb][j] = *reinterpret_cast<const f32x4*>(Bb + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
                 }
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < 3) load_frags(c + 1, (c + 1) & 1);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][k], bf[j][k], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][i][k], bf[c & 1][j][k], acc[i][j], 0, 0, 0);
             }
             if (s + 1 < s_end) store_step(buf ^ 1);
             __syncthreads();
@@ -165,50 +171,74 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     }
 
     // ------------------------------------------------------------------ epilogue
-    // C/D map of the 32x32 MFMA: col = lane&31 (n), row = (v&3) + 8*(v>>2) + 4*(lane>>5) (m).
-    const bool direct = (p.splitk == 1);
+    // Accumulators -> LDS (C layout, padded rows) -> 16-byte vector stores: one thread handles whole
+    // float4 chunks of a row, so bias / residual / output move as dwordx4 and the per-element address
+    // arithmetic of the 32x32 C/D map (col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)) disappears.
+    constexpr int LDC = BN + 4;
+    float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + fr;
-            if (n >= p.Cout) continue;
-            float bias = 0.f;
-            int co = n, g = 0;
-            if (direct) {
-                if (p.out_mode == 1) { g = n / p.cdec; co = n - g * p.cdec; }
-                if (p.bias) bias = p.bias[co];
-            }
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int m = m0 + (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * fh;
-                if (m >= M) continue;
-                float val = acc[i][j][v];
-                if (!direct) {
-                    p.ws[((size_t)z * p.M + m) * p.Cout + n] = val;
-                    continue;
-                }
-                val += bias;
+                const int row = (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * fh;
+                Cs[row * LDC + (wn * TN + j) * 32 + fr] = acc[i][j][v];
+            }
+    __syncthreads();
+    constexpr int C4 = BN / 4;                 // float4 chunks per tile row
+    constexpr int RPP = 256 / C4;              // rows covered per pass
+    const int c4 = tid % C4;
+    const int n = n0 + c4 * 4;
+    const bool direct = (p.splitk == 1);
+    const int ld_out = direct ? p.y_ld : p.Cout;
+    bool vec_ok;
+    if (!direct) vec_ok = (p.Cout & 3) == 0;
+    else if (p.out_mode == 1) vec_ok = (p.cdec & 3) == 0;
+    else vec_ok = ((ld_out & 3) == 0) && ((p.y_coff & 3) == 0) && (p.y_coff + n + 4 <= ld_out);
+    if (n < p.Cout) {
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        int co = n, g = 0;
+        if (direct) {
+            if (p.out_mode == 1) { g = n / p.cdec; co = n - g * p.cdec; }
+            if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);     // bias is padded to Cout_p
+        }
+        for (int r = tid / C4; r < BM; r += RPP) {
+            const int m = m0 + r;
+            if (m >= M) break;
+            f32x4 val = *reinterpret_cast<const f32x4*>(Cs + r * LDC + c4 * 4);
+            float* dst;
+            if (!direct) {
+                dst = p.ws + ((size_t)z * p.M + m) * p.Cout + n;
+            } else {
+                val += bias4;
                 if (p.out_mode == 0) {
                     if (p.res_mode == 1) {
-                        val += p.res[(size_t)m * p.Cout + n];
+                        val += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + n);
                     } else if (p.res_mode == 2) {
                         const int b = m / ohw;
                         const int rem = m - b * ohw;
                         const int oy = rem / p.OW, ox = rem - oy * p.OW;
                         const int hw2 = (p.OH >> 1) * (p.OW >> 1);
-                        val += p.res[((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n];
+                        val += *reinterpret_cast<const f32x4*>(
+                            p.res + ((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n);
                     }
-                    if (p.relu) val = val > 0.f ? val : 0.f;
-                    p.y[(size_t)m * p.y_ld + p.y_coff + n] = val;
+                    dst = p.y + (size_t)m * p.y_ld + p.y_coff + n;
                 } else {
                     const int b = m / ohw;
                     const int rem = m - b * ohw;
                     const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                    const int dy = g >> 1, dx = g & 1;
-                    if (p.relu) val = val > 0.f ? val : 0.f;
-                    p.y[(((size_t)b * 2 * p.OH + 2 * oy + dy) * (2 * p.OW) + 2 * ox + dx) * p.cdec + co] = val;
+                    dst = p.y + (((size_t)b * 2 * p.OH + 2 * oy + (g >> 1)) * (2 * p.OW) + 2 * ox + (g & 1)) * p.cdec + co;
                 }
+                if (p.relu) {
+                    val[0] = val[0] > 0.f ? val[0] : 0.f; val[1] = val[1] > 0.f ? val[1] : 0.f;
+                    val[2] = val[2] > 0.f ? val[2] : 0.f; val[3] = val[3] > 0.f ? val[3] : 0.f;
+                }
+            }
+            if (vec_ok) {
+                *reinterpret_cast<f32x4*>(dst) = val;
+            } else {
+                for (int k = 0; k < 4; ++k) if (n + k < p.Cout) dst[k] = val[k];
             }
         }
     }
@@ -258,7 +288,8 @@ template <int WM, int WN, int TM, int TN>
 static int launch_cfg(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
-    const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+    const size_t lds_stage = (size_t)2 * (BM + BN) * 32 * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+    const size_t lds = lds_stage > lds_c ? lds_stage : lds_c;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN>),
@@ -277,6 +308,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t s) {
 
 int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s) {
     if (p.M <= 0 || p.Cout <= 0 || p.steps_total <= 0) return APSE_E_INVALID;
+    if (p.res_mode != 0 && (p.Cout & 3) != 0) return APSE_E_INVALID;      // residual rows are read as float4
     switch (cfg) {
         case 0: return launch_cfg<2, 2, 2, 2>(p, s);
         case 1: return launch_cfg<2, 2, 1, 1>(p, s);
@@ -293,9 +325,11 @@ int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk) {
     if (Cout <= 32) return 2;
     if (Cout <= 64) return tiles(128, 64) >= 192 ? 3 : 1;
     if (tiles(128, 128) >= 224) return 0;
+    // 64x64 tiles: aim for >= 2 resident blocks per CU (each block is one wave per SIMD, so a second
+    // block is what hides the per-step barrier and LDS latency); split K across blocks to get there.
     int t = tiles(64, 64);
-    if (t < 128 && steps >= 16) {
-        int sk = (256 + t - 1) / t;
+    if (t < 384 && steps >= 16) {
+        int sk = (512 + t / 2) / t;
         if (sk > steps / 4) sk = steps / 4;
         if (sk > 64) sk = 64;
         if (sk < 1) sk = 1;

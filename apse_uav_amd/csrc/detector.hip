@@ -910,7 +910,7 @@ int apse_debug_tensor(apse_ctx* c, const char* name, void* dst, size_t max_bytes
     return APSE_OK;
 }
 
-double apse_flops(apse_ctx* c, int batch, int proposals, int detections) {
+double apse_flops(apse_ctx* c, int batch, double proposals, double detections) {
     if (!c || !c->finalized) return 0.0;
     double f = 0;
     for (auto& s : c->backbone) if (s.kind == S_CONV) f += s.c.flops_per_item * batch;

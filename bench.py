@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--blocks", type=str, default="3,4,23,3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
-    ap.add_argument("--bg-bias", type=float, default=1.2)
+    ap.add_argument("--bg-bias", type=float, default=None)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,7 +65,11 @@ def main():
     H, W = [int(v) for v in args.frame.split("x")]
     blocks = tuple(int(v) for v in args.blocks.split(","))
     B = args.batch
-    sd = synthetic_detector_state(0, blocks, bg_bias=args.bg_bias)
+    from apse_uav_amd.weights import UAV4K_R101_CLS_BIAS
+    if args.bg_bias is None and blocks == (3, 4, 23, 3):
+        sd = synthetic_detector_state(0, blocks, cls_bias=UAV4K_R101_CLS_BIAS)
+    else:
+        sd = synthetic_detector_state(0, blocks, bg_bias=args.bg_bias or 0.0)
     asd = synthetic_association_state(1)
     cfg = setup_cfg(device="cuda:%d" % local_rank)
     cfg.APSE.MAX_BATCH = B

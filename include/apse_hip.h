@@ -131,7 +131,7 @@ int apse_export_feature(apse_ctx* ctx, const char* name, float* dst_nchw_dev, in
 /* Debug/parity taps: copy a named intermediate (device, raw layout) to dst_dev; returns element count in *count. */
 int apse_debug_tensor(apse_ctx* ctx, const char* name, void* dst_dev, size_t max_bytes, size_t* bytes, void* stream);
 /* Algorithmic FLOPs of one forward for `batch` images with the given proposal/detection totals. */
-double apse_flops(apse_ctx* ctx, int batch, int proposals, int detections);
+double apse_flops(apse_ctx* ctx, int batch, double proposals, double detections);
 
 /* Per-kernel timing with HIP events on the caller's stream (one pair per convolution launch, collected at
  * apse_read_results).  out24 = [8 tile configs][3] = {sum ms, sum algorithmic FLOPs, launches}; configs
