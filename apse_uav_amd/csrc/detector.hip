@@ -33,7 +33,8 @@ int apse_k_rpn_topk_stage(const RpnLevels*, const TopkJob*, int, uint64_t*, int,
 int apse_k_rpn_decode(const RpnLevels*, int, const uint64_t*, int, const int*, float, float, float, float*, float*, int*,
                       uint32_t*, int, hipStream_t);
 int apse_k_nms_percat(const float*, const float*, const int*, int, int, int, const uint32_t*, float, int*, int*, int,
-                      const int*, int, hipStream_t);
+                      void*, int, hipStream_t);
+size_t apse_nms_scratch_bytes(int slots);
 int apse_k_rank_final(const float*, const float*, int, const int*, const int*, int, int, float*, float*, int*, int*, int,
                       hipStream_t);
 int apse_k_box_candidates(const float*, int, int, const float*, const int*, int, float, float, float, const float*, float,
@@ -86,7 +87,7 @@ struct apse_ctx {
     std::vector<std::vector<TopkJob>> stages; std::vector<TopkJob*> stage_dev; int nslots = 0; uint64_t* lists = nullptr;
     int final_slot_host[5]; int* final_slot_dev = nullptr;
     float *dec_boxes = nullptr, *dec_scores = nullptr; int* dec_valid = nullptr; uint32_t* maxc = nullptr;   // maxc[2*B]: rpn, box
-    int *keep_idx = nullptr, *keep_cnt = nullptr;
+    int *keep_idx = nullptr, *keep_cnt = nullptr; void* nms_scratch = nullptr;
     float *props = nullptr, *prop_scores = nullptr; int *prop_entry = nullptr;
     // box head
     FpnMaps fm;
@@ -97,6 +98,7 @@ struct apse_ctx {
     // mask tail
     uint64_t* bits = nullptr; unsigned long long* sums = nullptr; int wpr = 0;
     float* emb_raw = nullptr;
+    int hint_total = 8;      // detections seen in the previous forward: sizes the tiles of the packed-list GEMMs
     // per-kernel profiling with HIP events on the caller's stream (bench.py roofline)
     bool prof_on = false; std::vector<hipEvent_t> ev_pool; int ev_used = 0;
     struct Pending { int cfg; double flops_per_item; int count_kind; int b_mult; int batch; int e0, e1; };
@@ -272,6 +274,7 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     int sk = 1;
     cs.cfg = apse_conv_pick_cfg(Mfull, Cout, p.steps_total, &sk);
     p.splitk = sk;
+    if (count_kind == 2 && p.steps_total >= 16 && sk < 4) sk = 4;      // room for the hint-based split of small lists
     if (sk > 1) {
         const size_t need = (size_t)sk * Mfull * Cout;
         if (need > c->ws_floats) c->ws_floats = need;
@@ -292,17 +295,27 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
             p.M = p.B * p.OH * p.OW;
             p.ws = c->ws;
             p.m_count = nullptr; p.m_per_item = p.OH * p.OW;
-            if (st.c.count_kind == 2) p.m_count = total_dev;
+            int cfg = st.c.cfg;
+            if (st.c.count_kind == 2) {
+                p.m_count = total_dev;
+                // tile / split-K choice from the expected row count (any choice is correct for any count)
+                const int mh = (c->hint_total > 0 ? c->hint_total : 1) * p.m_per_item;
+                int sk = 1;
+                cfg = apse_conv_pick_cfg(mh < p.M ? mh : p.M, p.Cout, p.steps_total, &sk);
+                const size_t cap = c->ws_floats / ((size_t)p.M * p.Cout);
+                if ((size_t)sk > cap) sk = (int)cap;
+                p.splitk = sk < 1 ? 1 : sk;
+            }
             else if (st.c.count_kind == 1 && batch == 1) p.m_count = propcnt_dev;
             int e0 = -1;
             if (c->prof_on && c->ev_used + 2 <= (int)c->ev_pool.size()) {
                 e0 = c->ev_used; c->ev_used += 2;
                 hipEventRecord(c->ev_pool[e0], s);
             }
-            rc = apse_launch_conv(p, st.c.cfg, s);
+            rc = apse_launch_conv(p, cfg, s);
             if (e0 >= 0) {
                 hipEventRecord(c->ev_pool[e0 + 1], s);
-                c->pending.push_back({st.c.cfg, st.c.flops_per_item, st.c.count_kind, st.c.b_mult, batch, e0, e0 + 1});
+                c->pending.push_back({cfg, st.c.flops_per_item, st.c.count_kind, st.c.b_mult, batch, e0, e0 + 1});
             }
         } else if (st.kind == S_MAXPOOL) {
             rc = apse_k_maxpool3x3s2(st.x, st.y, batch, st.H, st.W, st.C, s);
@@ -492,6 +505,7 @@ static int build_plan(apse_ctx* c) {
     c->maxc = dalloc<uint32_t>(c, (size_t)2 * B);
     c->keep_idx = dalloc<int>(c, (size_t)B * 8 * NMS_SLOT);
     c->keep_cnt = dalloc<int>(c, (size_t)B * 8);
+    c->nms_scratch = dalloc<uint8_t>(c, apse_nms_scratch_bytes(8 * B));
     c->props = dalloc<float>(c, (size_t)B * POST * 4);
     c->prop_scores = dalloc<float>(c, (size_t)B * POST);
     c->prop_entry = dalloc<int>(c, (size_t)B * POST);
@@ -672,7 +686,7 @@ int apse_rpn(apse_ctx* c, int batch, void* stream) {
                            (float)log(1000.0 / 16.0), c->dec_boxes, c->dec_scores, c->dec_valid, c->maxc, batch, s);
     if (rc) return fail(c, rc, "rpn decode launch failed");
     rc = apse_k_nms_percat(c->dec_boxes, c->dec_scores, c->dec_valid, 5 * g.rpn_pre_topk, g.rpn_pre_topk, 0, c->maxc, g.rpn_nms,
-                           c->keep_idx, c->keep_cnt, 5, nullptr, batch, s);
+                           c->keep_idx, c->keep_cnt, 5, c->nms_scratch, batch, s);
     if (rc) return fail(c, rc, "rpn nms launch failed");
     int* propcnt = reinterpret_cast<int*>(c->res + c->lay.prop_count);
     rc = apse_k_rank_final(c->dec_boxes, c->dec_scores, 5 * g.rpn_pre_topk, c->keep_idx, c->keep_cnt, 5, g.rpn_post_topk, c->props,
@@ -707,7 +721,7 @@ int apse_box_head(apse_ctx* c, int batch, void* stream) {
                                c->maxc + g.max_batch, c->probs, batch, s);
     if (rc) return fail(c, rc, "box candidates launch failed");
     rc = apse_k_nms_percat(c->cand_boxes, c->cand_scores, c->cand_valid, P * K, 0, K, c->maxc + g.max_batch, g.box_nms, c->keep_idx,
-                           c->keep_cnt, K, nullptr, batch, s);
+                           c->keep_cnt, K, c->nms_scratch, batch, s);
     if (rc) return fail(c, rc, "box nms launch failed");
     rc = apse_k_rank_final(c->cand_boxes, c->cand_scores, P * K, c->keep_idx, c->keep_cnt, K, g.dets_per_image, c->det_boxes,
                            c->det_scores, c->det_entry, c->det_cnt, batch, s);
@@ -808,6 +822,7 @@ int apse_read_results(apse_ctx* c, void* host_dst, size_t bytes, void* stream) {
     if (bytes < c->lay.bytes) return fail(c, APSE_E_INVALID, "results buffer too small");
     HIPCHK(c, hipMemcpyAsync(host_dst, c->res, c->lay.bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+    c->hint_total = *reinterpret_cast<const int*>(reinterpret_cast<const uint8_t*>(host_dst) + c->lay.total);
     if (c->prof_on) {
         const uint8_t* h = reinterpret_cast<const uint8_t*>(host_dst);
         const int total = *reinterpret_cast<const int*>(h + c->lay.total);
@@ -1018,10 +1033,12 @@ int apse_nms_rank(const float* boxes, const float* scores, const int* valid, int
     uint32_t mb;
     memcpy(&mb, &m, 4);
     hipMemcpy(maxc, &mb, 4, hipMemcpyHostToDevice);
-    int rc = apse_k_nms_percat(boxes, scores, valid, n, cat_div, cat_mod, maxc, thr, keep_idx, keep_cnt, ncat, nullptr, 1, s);
+    void* scratch = nullptr;
+    if (hipMalloc(&scratch, apse_nms_scratch_bytes(8)) != hipSuccess) return APSE_E_NOMEM;
+    int rc = apse_k_nms_percat(boxes, scores, valid, n, cat_div, cat_mod, maxc, thr, keep_idx, keep_cnt, ncat, scratch, 1, s);
     if (!rc) rc = apse_k_rank_final(boxes, scores, n, keep_idx, keep_cnt, ncat, topk, out_boxes, out_scores, out_index, out_count, 1, s);
     hipStreamSynchronize(s);
-    hipFree(keep_idx); hipFree(keep_cnt); hipFree(maxc);
+    hipFree(keep_idx); hipFree(keep_cnt); hipFree(maxc); hipFree(scratch);
     return rc;
 }
 

@@ -14,7 +14,6 @@
 
 #define TK_N 4096          // elements sorted per block in the top-k tournament
 #define NMS_MAX 1024       // boxes per category (<= 1000 by construction)
-#define RANK_N 8192        // final ranking capacity
 
 __device__ __forceinline__ uint32_t mono_key(float f) {   // order-preserving float -> uint
     uint32_t u = __float_as_uint(f);
@@ -36,17 +35,18 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {   // l must 
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Bitonic sort of N (power of two) 64-bit keys in LDS, ascending.  Pair-indexed: every thread
+// owns whole compare-exchange pairs, so no lane idles on the "partner > self" test.
 template <int N, int THREADS>
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int tid) {
     for (int k = 2; k <= N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < N; i += THREADS) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const bool asc = (i & k) == 0;
-                    const uint64_t x = a[i], y = a[ixj];
-                    if ((x > y) == asc) { a[i] = y; a[ixj] = x; }
-                }
+            for (int pidx = tid; pidx < N / 2; pidx += THREADS) {
+                const int i = ((pidx & ~(j - 1)) << 1) | (pidx & (j - 1));
+                const int l = i | j;
+                const bool asc = (i & k) == 0;
+                const uint64_t x = a[i], y = a[l];
+                if ((x > y) == asc) { a[i] = y; a[l] = x; }
             }
             __syncthreads();
         }
@@ -158,35 +158,35 @@ __global__ __launch_bounds__(256) void rpn_decode(const RpnLevels* __restrict__ 
 }
 
 // ---------------------------------------------------------------- per-category NMS
-// One block per (category, image).  Entries: boxes/scores/valid are [B][n_total]; the category of
-// entry e is  cat_div ? e / cat_div : e % cat_mod .  Within the category, entries are ordered by
-// (score desc, entry index asc), IoU is evaluated on boxes shifted by cat * (max_coord + 1) in f32
-// (torchvision batched_nms), `iou > thr` suppresses.  Output: kept entry indices in that order.
-__global__ __launch_bounds__(1024) void nms_percat(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                   const int* __restrict__ valid, int n_total, int cat_div, int cat_mod,
-                                                   const uint32_t* __restrict__ maxc, float thr, int* __restrict__ keep_idx,
-                                                   int* __restrict__ keep_cnt, int ncat, const int* __restrict__ n_limit) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* mask = reinterpret_cast<uint64_t*>(smem);                      // [NMS_MAX][16]  (128 KB)
-    uint64_t* keys = mask + (size_t)NMS_MAX * 16;                            // [NMS_MAX]      (8 KB)
-    float* bx = reinterpret_cast<float*>(keys + NMS_MAX);                    // [4][NMS_MAX]   (16 KB)
-    float* area = bx + 4 * NMS_MAX;                                          // [NMS_MAX]      (4 KB)
-    int* wsum = reinterpret_cast<int*>(area + NMS_MAX);                      // [17]
+// Entries: boxes/scores/valid are [B][n_total]; the category of entry e is
+// cat_div ? e / cat_div : e % cat_mod.  Within a category, entries are ordered by (score desc,
+// entry index asc); IoU is evaluated on boxes shifted by cat * (max_coord + 1) in f32 (torchvision
+// batched_nms); `iou > thr` suppresses.  Three launches:
+//   nms_prepare : one block per (category, image): ordered compaction + sort -> sorted shifted boxes
+//   nms_matrix  : 64x64 tiles of the upper-triangular suppression bit matrix, one wave each
+//   nms_scan    : one block per (category, image): greedy scan, 64 rows at a time
+// scratch per (image, category): entry[1024] int, box[4][1024] f32, area[1024] f32, mask[1024][16] u64, n.
+struct NmsScratch {
+    int* entry; float* box; float* area; uint64_t* mask; int* n;
+};
+
+__global__ __launch_bounds__(1024) void nms_prepare(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                    const int* __restrict__ valid, int n_total, int cat_div, int cat_mod,
+                                                    const uint32_t* __restrict__ maxc, NmsScratch S, int ncat) {
+    __shared__ uint64_t keys[NMS_MAX];
+    __shared__ int wsum[17];
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     boxes += (size_t)b * n_total * 4;
     scores += (size_t)b * n_total;
     valid += (size_t)b * n_total;
-    int nt = n_total;
-    if (n_limit) { const int lim = n_limit[b]; nt = lim < nt ? lim : nt; }
-
-    // 1. ordered compaction of this category's valid entries
+    const size_t slot = (size_t)b * ncat + c;
     if (tid == 0) wsum[16] = 0;
-    for (int i = tid; i < NMS_MAX; i += 1024) keys[i] = ~0ull;
+    keys[tid] = ~0ull;
     __syncthreads();
-    for (int base = 0; base < nt; base += 1024) {
+    for (int base = 0; base < n_total; base += 1024) {
         const int e = base + tid;
         bool f = false;
-        if (e < nt) {
+        if (e < n_total) {
             const int cat = cat_div ? e / cat_div : e % cat_mod;
             f = (cat == c) && valid[e];
         }
@@ -203,121 +203,161 @@ __global__ __launch_bounds__(1024) void nms_percat(const float* __restrict__ box
     }
     int n = wsum[16];
     n = n < NMS_MAX ? n : NMS_MAX;
-    // 2. sort by (score desc, index asc)
     bitonic_sort_lds<NMS_MAX, 1024>(keys, tid);
-    // 3. shifted boxes + areas
     const float off = (float)c * (__uint_as_float(maxc[b]) + 1.0f);
+    float* bx = S.box + slot * 4 * NMS_MAX;
     if (tid < n) {
         const uint32_t e = (uint32_t)keys[tid];
         const float x0 = boxes[e * 4 + 0] + off, y0 = boxes[e * 4 + 1] + off;
         const float x1 = boxes[e * 4 + 2] + off, y1 = boxes[e * 4 + 3] + off;
         bx[tid] = x0; bx[NMS_MAX + tid] = y0; bx[2 * NMS_MAX + tid] = x1; bx[3 * NMS_MAX + tid] = y1;
-        area[tid] = (x1 - x0) * (y1 - y0);
+        S.area[slot * NMS_MAX + tid] = (x1 - x0) * (y1 - y0);
+        S.entry[slot * NMS_MAX + tid] = (int)e;
+    }
+    if (tid == 0) S.n[slot] = n;
+}
+
+// grid (16 column chunks, 16 row chunks, ncat*B), 64 threads: thread t owns row 64*ic + t.
+__global__ __launch_bounds__(64) void nms_matrix(NmsScratch S, float thr) {
+    __shared__ float cb[5][64];
+    const int jc = blockIdx.x, ic = blockIdx.y;
+    const size_t slot = blockIdx.z;
+    const int n = S.n[slot];
+    if (jc < ic || 64 * ic >= n || 64 * jc >= n) return;
+    const int t = threadIdx.x;
+    const float* bx = S.box + slot * 4 * NMS_MAX;
+    const float* ar = S.area + slot * NMS_MAX;
+    const int j = 64 * jc + t;
+    if (j < n) {
+        cb[0][t] = bx[j]; cb[1][t] = bx[NMS_MAX + j]; cb[2][t] = bx[2 * NMS_MAX + j]; cb[3][t] = bx[3 * NMS_MAX + j];
+        cb[4][t] = ar[j];
     }
     __syncthreads();
-    // 4. suppression bit-matrix: mask[i][w] bit j  <=>  IoU(i, 64w+j) > thr, for 64w+j > i
-    const int nw = (n + 63) >> 6;
-    for (int item = tid; item < n * nw; item += 1024) {
-        const int i = item / nw, w = item - i * nw;
-        uint64_t bits = 0;
-        if (64 * w + 63 > i) {
-            const float ix0 = bx[i], iy0 = bx[NMS_MAX + i], ix1 = bx[2 * NMS_MAX + i], iy1 = bx[3 * NMS_MAX + i];
-            const float ia = area[i];
-            const int j0 = 64 * w;
-            const int jend = (n - j0) < 64 ? (n - j0) : 64;
-            for (int jj = 0; jj < jend; ++jj) {
-                const int j = j0 + jj;
-                if (j <= i) continue;
-                const float xx0 = fmaxf(ix0, bx[j]), yy0 = fmaxf(iy0, bx[NMS_MAX + j]);
-                const float xx1 = fminf(ix1, bx[2 * NMS_MAX + j]), yy1 = fminf(iy1, bx[3 * NMS_MAX + j]);
-                const float ww = fmaxf(0.f, xx1 - xx0), hh = fmaxf(0.f, yy1 - yy0);
-                const float inter = ww * hh;
-                const float ovr = inter / (ia + area[j] - inter);
-                if (ovr > thr) bits |= (1ull << jj);
-            }
+    const int i = 64 * ic + t;
+    uint64_t bits = 0;
+    if (i < n) {
+        const float ix0 = bx[i], iy0 = bx[NMS_MAX + i], ix1 = bx[2 * NMS_MAX + i], iy1 = bx[3 * NMS_MAX + i];
+        const float ia = ar[i];
+        const int jend = (n - 64 * jc) < 64 ? (n - 64 * jc) : 64;
+        for (int jj = 0; jj < jend; ++jj) {
+            if (64 * jc + jj <= i) continue;
+            const float xx0 = fmaxf(ix0, cb[0][jj]), yy0 = fmaxf(iy0, cb[1][jj]);
+            const float xx1 = fminf(ix1, cb[2][jj]), yy1 = fminf(iy1, cb[3][jj]);
+            const float ww = fmaxf(0.f, xx1 - xx0), hh = fmaxf(0.f, yy1 - yy0);
+            const float inter = ww * hh;
+            const float ovr = inter / (ia + cb[4][jj] - inter);
+            if (ovr > thr) bits |= (1ull << jj);
         }
-        mask[(size_t)i * 16 + w] = bits;
     }
+    S.mask[(slot * NMS_MAX + i) * 16 + jc] = bits;
+}
+
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+    return v;
+}
+
+// Greedy scan, one block per (category, image).  Wave 0 resolves the 64 rows of a chunk on the
+// diagonal word (scalar readlanes), then wave w ORs the kept rows' word w into the removed bitmap.
+__global__ __launch_bounds__(1024) void nms_scan(NmsScratch S, int* __restrict__ keep_idx, int* __restrict__ keep_cnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* mask = reinterpret_cast<uint64_t*>(smem);          // [n][16]
+    __shared__ uint64_t removed[16];
+    __shared__ uint64_t keepbits_s;
+    const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = S.n[slot];
+    const int nw = (n + 63) >> 6;
+    const uint64_t* gm = S.mask + slot * NMS_MAX * 16;
+    for (int i = tid; i < n * 16; i += 1024) {
+        const int r = i >> 4, w = i & 15;
+        mask[i] = (w >= (r >> 6) && w < nw) ? gm[i] : 0ull;       // lower-triangle words were never written
+    }
+    if (tid < 16) removed[tid] = 0;
     __syncthreads();
-    // 5. greedy scan (wave 0): 64 rows at a time; the in-chunk dependency is resolved on the
-    //    diagonal word with scalar reads, then the kept rows' words are OR-reduced into `removed`.
-    if (wave == 0) {
-        uint64_t removed = 0;          // lane w (< 16) owns word w of the removed bitmap
-        int kept = 0;
-        int* out = keep_idx + ((size_t)b * ncat + c) * NMS_MAX;
-        for (int ch = 0; ch < nw; ++ch) {
+    int kept = 0;
+    int* out = keep_idx + slot * NMS_MAX;
+    const int* entry = S.entry + slot * NMS_MAX;
+    for (int ch = 0; ch < nw; ++ch) {
+        const int rows_here = (n - 64 * ch) < 64 ? (n - 64 * ch) : 64;
+        if (wave == 0) {
             const int row = 64 * ch + lane;
             const uint64_t diag = row < n ? mask[(size_t)row * 16 + ch] : 0ull;
-            uint64_t rem = readlane64(removed, ch);
+            uint64_t rem = removed[ch];
             uint64_t keepbits = 0;
-            const int rows_here = (n - 64 * ch) < 64 ? (n - 64 * ch) : 64;
             for (int r = 0; r < rows_here; ++r) {
                 if (!((rem >> r) & 1ull)) {
                     keepbits |= (1ull << r);
                     rem |= readlane64(diag, r);
                 }
             }
-            // write kept entries of this chunk in order
-            if ((keepbits >> lane) & 1ull) {
-                const int pos = kept + __popcll(keepbits & ((1ull << lane) - 1ull));
-                out[pos] = (int)(uint32_t)keys[row];
-            }
+            if ((keepbits >> lane) & 1ull) out[kept + __popcll(keepbits & ((1ull << lane) - 1ull))] = entry[row];
             kept += __popcll(keepbits);
-            // removed[w] |= OR_{kept rows r} mask[64ch+r][w]   (lane = w)
-            if (lane < nw) {
-                uint64_t acc = 0;
-                for (int r = 0; r < rows_here; ++r)
-                    if ((keepbits >> r) & 1ull) acc |= mask[(size_t)(64 * ch + r) * 16 + lane];
-                removed |= acc;
-            }
+            if (lane == 0) keepbits_s = keepbits;
         }
-        if (lane == 0) keep_cnt[b * ncat + c] = kept;
+        __syncthreads();
+        if (wave > ch && wave < nw) {
+            const uint64_t kb = keepbits_s;
+            uint64_t v = 0;
+            if (lane < rows_here && ((kb >> lane) & 1ull)) v = mask[(size_t)(64 * ch + lane) * 16 + wave];
+            v = wave_or64(v);
+            if (lane == 0) removed[wave] |= v;
+        }
+        __syncthreads();
     }
+    if (tid == 0) keep_cnt[slot] = kept;
 }
 
-// Final ranking: all kept entries of all categories by (score desc, entry index asc); first K.
-// Writes boxes/scores/entry index of the winners and their count.
-__global__ __launch_bounds__(1024) void rank_final(const float* __restrict__ boxes, const float* __restrict__ scores,
+// Final ranking by merging: each category's kept list is already sorted by (score desc, entry asc),
+// so the global rank of an element is its own position plus, for every other list, the number of
+// keys that precede it (binary search).  No barriers after the load; first K ranks are written.
+__global__ __launch_bounds__(1024) void rank_merge(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                    int n_total, const int* __restrict__ keep_idx,
                                                    const int* __restrict__ keep_cnt, int ncat, int K,
                                                    float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                                    int* __restrict__ out_entry, int* __restrict__ out_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* a = reinterpret_cast<uint64_t*>(smem);    // [RANK_N]
-    __shared__ int total;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);      // [ncat][NMS_MAX]
+    __shared__ int cnt[8];
     const int b = blockIdx.x, tid = threadIdx.x;
     boxes += (size_t)b * n_total * 4;
     scores += (size_t)b * n_total;
-    for (int i = tid; i < RANK_N; i += 1024) a[i] = ~0ull;
+    if (tid < ncat) cnt[tid] = keep_cnt[b * ncat + tid];
     __syncthreads();
-    int base = 0;
+    int total = 0;
     for (int c = 0; c < ncat; ++c) {
-        const int cnt = keep_cnt[b * ncat + c];
         const int* src = keep_idx + ((size_t)b * ncat + c) * NMS_MAX;
-        for (int i = tid; i < cnt; i += 1024) {
-            const int e = src[i];
-            if (base + i < RANK_N) a[base + i] = comp_key(scores[e], (uint32_t)e);
-        }
-        base += cnt;
+        if (tid < cnt[c]) { const int e = src[tid]; keys[c * NMS_MAX + tid] = comp_key(scores[e], (uint32_t)e); }
+        total += cnt[c];
     }
-    if (tid == 0) total = base < RANK_N ? base : RANK_N;
     __syncthreads();
-    bitonic_sort_lds<RANK_N, 1024>(a, tid);
-    const int n = total < K ? total : K;
-    for (int i = tid; i < K; i += 1024) {
-        float* ob = out_boxes + ((size_t)b * K + i) * 4;
-        if (i < n) {
-            const uint32_t e = (uint32_t)a[i];
+    const int nout = total < K ? total : K;
+    for (int c = 0; c < ncat; ++c) {
+        if (tid >= cnt[c]) continue;
+        const uint64_t key = keys[c * NMS_MAX + tid];
+        int rank = tid;
+        for (int o = 0; o < ncat; ++o) {
+            if (o == c) continue;
+            int lo = 0, hi = cnt[o];
+            const uint64_t* ko = keys + o * NMS_MAX;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ko[mid] < key) lo = mid + 1; else hi = mid; }
+            rank += lo;
+        }
+        if (rank < K) {
+            const uint32_t e = (uint32_t)key;
+            float* ob = out_boxes + ((size_t)b * K + rank) * 4;
             ob[0] = boxes[e * 4 + 0]; ob[1] = boxes[e * 4 + 1]; ob[2] = boxes[e * 4 + 2]; ob[3] = boxes[e * 4 + 3];
-            out_scores[(size_t)b * K + i] = scores[e];
-            out_entry[(size_t)b * K + i] = (int)e;
-        } else {
-            ob[0] = ob[1] = ob[2] = ob[3] = 0.f;
-            out_scores[(size_t)b * K + i] = 0.f;
-            out_entry[(size_t)b * K + i] = -1;
+            out_scores[(size_t)b * K + rank] = scores[e];
+            out_entry[(size_t)b * K + rank] = (int)e;
         }
     }
-    if (tid == 0) out_count[b] = n;
+    for (int i = nout + tid; i < K; i += 1024) {
+        float* ob = out_boxes + ((size_t)b * K + i) * 4;
+        ob[0] = ob[1] = ob[2] = ob[3] = 0.f;
+        out_scores[(size_t)b * K + i] = 0.f;
+        out_entry[(size_t)b * K + i] = -1;
+    }
+    if (tid == 0) out_count[b] = nout;
 }
 
 // ---------------------------------------------------------------- box head post-processing
@@ -412,18 +452,33 @@ int apse_k_rpn_decode(const RpnLevels* L_dev, int pre_topk, const uint64_t* list
                        img_h, img_w, scale_clamp, boxes, scores, valid, maxc);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
-static size_t nms_lds_bytes() { return (size_t)NMS_MAX * 16 * 8 + NMS_MAX * 8 + 5 * NMS_MAX * 4 + 32 * 4; }
+size_t apse_nms_scratch_bytes(int slots) {
+    return (size_t)slots * (NMS_MAX * 4 + 4 * NMS_MAX * 4 + NMS_MAX * 4 + (size_t)NMS_MAX * 16 * 8 + 16);
+}
+static NmsScratch carve(void* scratch, int slots) {
+    NmsScratch S;
+    char* p = reinterpret_cast<char*>(scratch);
+    S.mask = reinterpret_cast<uint64_t*>(p); p += (size_t)slots * NMS_MAX * 16 * 8;
+    S.box = reinterpret_cast<float*>(p); p += (size_t)slots * 4 * NMS_MAX * 4;
+    S.area = reinterpret_cast<float*>(p); p += (size_t)slots * NMS_MAX * 4;
+    S.entry = reinterpret_cast<int*>(p); p += (size_t)slots * NMS_MAX * 4;
+    S.n = reinterpret_cast<int*>(p);
+    return S;
+}
 int apse_k_nms_percat(const float* boxes, const float* scores, const int* valid, int n_total, int cat_div, int cat_mod,
-                      const uint32_t* maxc, float thr, int* keep_idx, int* keep_cnt, int ncat, const int* n_limit, int B,
+                      const uint32_t* maxc, float thr, int* keep_idx, int* keep_cnt, int ncat, void* scratch, int B,
                       hipStream_t s) {
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_percat), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)nms_lds_bytes());
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            NMS_MAX * 16 * 8);
         done = true;
     }
-    hipLaunchKernelGGL(nms_percat, dim3(ncat, B), dim3(1024), nms_lds_bytes(), s, boxes, scores, valid, n_total, cat_div,
-                       cat_mod, maxc, thr, keep_idx, keep_cnt, ncat, n_limit);
+    NmsScratch S = carve(scratch, ncat * B);
+    hipLaunchKernelGGL(nms_prepare, dim3(ncat, B), dim3(1024), 0, s, boxes, scores, valid, n_total, cat_div, cat_mod, maxc, S,
+                       ncat);
+    hipLaunchKernelGGL(nms_matrix, dim3(16, 16, ncat * B), dim3(64), 0, s, S, thr);
+    hipLaunchKernelGGL(nms_scan, dim3(ncat, B), dim3(1024), NMS_MAX * 16 * 8, s, S, keep_idx, keep_cnt);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_rank_final(const float* boxes, const float* scores, int n_total, const int* keep_idx, const int* keep_cnt,
@@ -431,12 +486,13 @@ int apse_k_rank_final(const float* boxes, const float* scores, int n_total, cons
                       hipStream_t s) {
     static bool done = false;
     if (!done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_final), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            RANK_N * 8);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_merge), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            8 * NMS_MAX * 8);
         done = true;
     }
-    hipLaunchKernelGGL(rank_final, dim3(B), dim3(1024), RANK_N * 8, s, boxes, scores, n_total, keep_idx, keep_cnt, ncat, K,
-                       out_boxes, out_scores, out_entry, out_count);
+    if (ncat > 8) return APSE_E_INVALID;
+    hipLaunchKernelGGL(rank_merge, dim3(B), dim3(1024), (size_t)ncat * NMS_MAX * 8, s, boxes, scores, n_total, keep_idx, keep_cnt,
+                       ncat, K, out_boxes, out_scores, out_entry, out_count);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_box_candidates(const float* pred, int ld, int K, const float* props, const int* prop_cnt, int P, float img_h,

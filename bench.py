@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--blocks", type=str, default="3,4,23,3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP-event timing (no roofline block)")
     ap.add_argument("--bg-bias", type=float, default=None)
     args = ap.parse_args()
 
@@ -103,7 +104,7 @@ def main():
     for i in range(args.warmup):
         res = step(i, False)
     torch.cuda.synchronize()
-    _lib.check(lib.apse_profile(model._ctx, 1), model._ctx, "apse_profile")
+    _lib.check(lib.apse_profile(model._ctx, 0 if args.no_events else 1), model._ctx, "apse_profile")
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Per-layer convolution efficiency from a rocprofv3 --kernel-trace CSV of bench.py (last frame)."""
+import collections
+import csv
+import sys
+
+path = sys.argv[1]
+ndet = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+rows = list(csv.DictReader(open(path)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('pil_resize_h')]
+fr = rows[idx[-2]:idx[-1]]
+t0 = int(fr[0]['Start_Timestamp'])
+span = (int(fr[-1]['End_Timestamp']) - t0) / 1e3
+busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in fr) / 1e3
+print('frame: %d kernels, span %.1f us, busy %.1f us' % (len(fr), span, busy))
+layers = []
+
+
+def conv(name, M, Cout, K):
+    layers.append((name, M, Cout, K, 2.0 * M * Cout * K))
+
+
+H, W = 768, 1344
+conv('stem', (H // 2) * (W // 2), 64, 147)
+h, w, cin = H // 4, W // 4, 64
+for si, nb in enumerate((3, 4, 23, 3)):
+    mid = 64 * 2 ** si
+    cout = 4 * mid
+    for bi in range(nb):
+        st = 2 if (bi == 0 and si > 0) else 1
+        oh, ow = h // st, w // st
+        if bi == 0:
+            conv('res%d.sc' % (si + 2), oh * ow, cout, cin)
+        conv('res%d.c1' % (si + 2), oh * ow, mid, cin)
+        conv('res%d.c2' % (si + 2), oh * ow, mid, mid * 9)
+        conv('res%d.c3' % (si + 2), oh * ow, cout, mid)
+        h, w, cin = oh, ow, cout
+dims = {2: (192, 336, 256), 3: (96, 168, 512), 4: (48, 84, 1024), 5: (24, 42, 2048)}
+for l in (5, 4, 3, 2):
+    hh, ww, c = dims[l]
+    conv('lat%d' % l, hh * ww, 256, c)
+    conv('out%d' % l, hh * ww, 256, 256 * 9)
+for l, (hh, ww) in enumerate([(192, 336), (96, 168), (48, 84), (24, 42), (12, 21)]):
+    conv('rpn_t%d' % (l + 2), hh * ww, 256, 2304)
+    conv('rpn_h%d' % (l + 2), hh * ww, 15, 256)
+conv('fc1', 1000, 1024, 12544)
+conv('fc2', 1000, 1024, 1024)
+conv('pred', 1000, 21, 1024)
+for i in range(4):
+    conv('mask%d' % i, ndet * 196, 256, 2304)
+conv('deconv', ndet * 196, 1024, 256)
+conv('mlogit', ndet * 784, 4, 256)
+conv('assoc', ndet, 128, 25600)
+# attribute split-K reduce kernels to the preceding conv
+items = []
+for r in fr:
+    kn = r['Kernel_Name']
+    d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    if kn.startswith('void conv_igemm'):
+        items.append([kn.split('<')[1].split('>')[0], d, r['Grid_Size_X'], r['Grid_Size_Y']])
+    elif kn.startswith('conv_splitk_reduce') and items:
+        items[-1][1] += d
+assert len(items) == len(layers), (len(items), len(layers))
+agg = collections.OrderedDict()
+tot = 0
+for (name, M, Cout, K, fl), (cfg, d, gx, gy) in zip(layers, items):
+    a = agg.setdefault((name, cfg, M, Cout, K, gx, gy), [0, 0, 0])
+    a[0] += d
+    a[1] += fl
+    a[2] += 1
+    tot += d
+print('conv total %.1f us' % tot)
+for k, (d, fl, n) in agg.items():
+    print('%-8s <%s> M=%6d N=%5d K=%5d grid=%sx%s n=%2d %8.1f us %6.1f TF' % (k[0], k[1], k[2], k[3], k[4], k[5], k[6], n, d, fl / d / 1e6))
+others = collections.Counter()
+for r in fr:
+    kn = r['Kernel_Name']
+    if not (kn.startswith('void conv_igemm') or kn.startswith('conv_splitk_reduce')):
+        others[kn.split('(')[0][:40]] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+print('non-conv kernels:')
+for k, v in others.most_common(14):
+    print('  %-42s %8.1f us' % (k, v))
