@@ -14,25 +14,29 @@
 // bank-conflict-free (MI355X_MICROARCH.md, LDS table: b128 reads are served per 16-lane group
 // over 64 banks).  One ds_read_b128 feeds FOUR MFMA k-steps: lane half h takes k = 8c+4h+j for
 // step j (the k order inside a chunk is a free choice as long as A and B agree).
-// Global->LDS staging goes through registers (issue loads for step s+1, run the MFMAs of step
-// s, then write LDS): an f32 MFMA k-step is 4096 cycles/wave at 128x128, so the loads are
-// always back before they are needed; one barrier per k-step.
+// Global->LDS staging goes through two register sets: the loads of k-step s+2 are issued before
+// the MFMAs of step s and written to LDS after the MFMAs of step s+1 (an f32 MFMA k-step is
+// 1024 cycles/wave at 64x64 and 4096 at 128x128); one barrier per k-step.
 #include "apse_common.h"
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int KS>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int AP = BM / 32;   // staging passes (32 rows x 8 slots of 16 B per pass)
     constexpr int BP = BN / 32;
+    constexpr int LDC = BN + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* As = reinterpret_cast<float*>(smem);   // [2][BM*32]
-    float* Bs = As + 2 * BM * 32;                 // [2][BN*32]
+    float* As = reinterpret_cast<float*>(smem);   // [2][KS][BM*32]
+    float* Bs = As + 2 * KS * BM * 32;            // [2][KS][BN*32]
+    float* Cs = reinterpret_cast<float*>(smem);   // epilogue view [BM][LDC]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int srow = tid >> 3, slot = tid & 7;
 
     int M = p.M;
     if (p.m_count) {
@@ -40,207 +44,220 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
         M = lim < M ? lim : M;
     }
     const int tiles_n = (p.Cout + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
-    // XCD-aware remap (blocks are dealt round-robin over 8 XCDs): give each XCD a contiguous
-    // range of tiles so neighbours that share an activation tile share an L2.  Bijective form.
+    const int tiles_m = (M + BM - 1) / BM;        // live tiles only (M may come from a device count)
     const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    if (m0 >= M) return;
-
     const int z = blockIdx.y;
-    const int per = (p.steps_total + p.splitk - 1) / p.splitk;
+    // a "step" is KS sub-steps of 32 k each between two barriers (KS = 2 for the small tiles, whose
+    // 1024-cycle MFMA sub-step is too short to cover an L2/HBM round trip)
+    const int steps_big = (p.steps_total + KS - 1) / KS;
+    const int per = (steps_big + p.splitk - 1) / p.splitk;
     const int s_begin = z * per;
-    const int s_end = (s_begin + per < p.steps_total) ? s_begin + per : p.steps_total;
+    const int s_end = (s_begin + per < steps_big) ? s_begin + per : steps_big;
     const int steps_per_row = p.KWCp >> 5;
-
-    // per-thread staging rows
-    const int srow = tid >> 3, slot = tid & 7;
-    int a_iy0[AP], a_ix0[AP], a_pix[AP];
     const int ohw = p.OH * p.OW;
-#pragma unroll
-    for (int i = 0; i < AP; ++i) {
-        const int m = m0 + srow + 32 * i;
-        if (m < M) {
-            const int b = m / ohw;
-            const int rem = m - b * ohw;
-            const int oy = rem / p.OW;
-            const int ox = rem - oy * p.OW;
-            a_iy0[i] = oy * p.stride - p.pad;
-            a_ix0[i] = ox * p.stride - p.pad;
-            a_pix[i] = b * p.H * p.W;
-        } else {
-            a_iy0[i] = -(1 << 28);   // never valid
-            a_ix0[i] = 0;
-            a_pix[i] = 0;
-        }
-    }
     const size_t w_row = (size_t)p.KH * p.KWCp;
-
-    f32x4 ra[AP], rb[BP];
-    auto load_step = [&](int s) {
-        const int r = s / steps_per_row;
-        const int q = ((s - r * steps_per_row) << 5) + (slot << 2);
-        const int dpx = q >> p.cin_log2;
-#pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            const int iy = a_iy0[i] + r;
-            const int px = a_ix0[i] + dpx;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)iy < (unsigned)p.H && (unsigned)px < (unsigned)p.W) {
-                const int off = ((a_pix[i] + iy * p.W + a_ix0[i]) << p.cin_log2) + q;
-                v = *reinterpret_cast<const f32x4*>(p.x + off);
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BP; ++i) {
-            const int n = n0 + srow + 32 * i;
-            rb[i] = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * w_row + (size_t)r * p.KWCp + q);
-        }
-    };
-    auto store_step = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            const int row = srow + 32 * i;
-            const int ps = slot ^ ((row >> 1) & 7);
-            *reinterpret_cast<f32x4*>(As + buf * BM * 32 + row * 32 + ps * 4) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < BP; ++i) {
-            const int row = srow + 32 * i;
-            const int ps = slot ^ ((row >> 1) & 7);
-            *reinterpret_cast<f32x4*>(Bs + buf * BN * 32 + row * 32 + ps * 4) = rb[i];
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-
-    const int fr = lane & 31, fh = lane >> 5;
-    if (s_begin < s_end) {
-        load_step(s_begin);
-        store_step(0);
-        __syncthreads();
-        for (int s = s_begin; s < s_end; ++s) {
-            const int buf = (s - s_begin) & 1;
-            if (s + 1 < s_end) load_step(s + 1);
-            const float* Ab = As + buf * BM * 32;
-            const float* Bb = Bs + buf * BN * 32;
-            // fragments are double-buffered in registers: the ds_read_b128s of chunk c+1 are issued
-            // before the MFMAs of chunk c, so LDS latency hides behind the matrix pipe.
-            f32x4 af[2][TM], bf[2][TN];
-            auto load_frags = [&](int c, int fb) {
-                const int ls = 2 * c + fh;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = (wm * TM + i) * 32 + fr;
-                    af[fb][i] = *reinterpret_cast<const f32x4*>(Ab + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int row = (wn * TN + j) * 32 + fr;
-                    bf[fb][j] = *reinterpret_cast<const f32x4*>(Bb + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
-                }
-            };
-            load_frags(0, 0);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c < 3) load_frags(c + 1, (c + 1) & 1);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][i][k], bf[c & 1][j][k], acc[i][j], 0, 0, 0);
-            }
-            if (s + 1 < s_end) store_step(buf ^ 1);
-            __syncthreads();
-        }
-    }
-
-    // ------------------------------------------------------------------ epilogue
-    // Accumulators -> LDS (C layout, padded rows) -> 16-byte vector stores: one thread handles whole
-    // float4 chunks of a row, so bias / residual / output move as dwordx4 and the per-element address
-    // arithmetic of the 32x32 C/D map (col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)) disappears.
-    constexpr int LDC = BN + 4;
-    float* Cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int row = (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * fh;
-                Cs[row * LDC + (wn * TN + j) * 32 + fr] = acc[i][j][v];
-            }
-    __syncthreads();
-    constexpr int C4 = BN / 4;                 // float4 chunks per tile row
-    constexpr int RPP = 256 / C4;              // rows covered per pass
-    const int c4 = tid % C4;
-    const int n = n0 + c4 * 4;
     const bool direct = (p.splitk == 1);
-    const int ld_out = direct ? p.y_ld : p.Cout;
-    bool vec_ok;
-    if (!direct) vec_ok = (p.Cout & 3) == 0;
-    else if (p.out_mode == 1) vec_ok = (p.cdec & 3) == 0;
-    else vec_ok = ((ld_out & 3) == 0) && ((p.y_coff & 3) == 0) && (p.y_coff + n + 4 <= ld_out);
-    if (n < p.Cout) {
-        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-        int co = n, g = 0;
-        if (direct) {
-            if (p.out_mode == 1) { g = n / p.cdec; co = n - g * p.cdec; }
-            if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);     // bias is padded to Cout_p
+
+    // Persistent over tiles: the grid is min(tiles, cap); count-limited launches (packed detection
+    // lists) therefore spend nothing on tiles past the device-side count.
+    for (int wg = blockIdx.x; wg < nwg; wg += gridDim.x) {
+        // XCD-aware remap (blocks are dealt round-robin over 8 XCDs): give each XCD a contiguous
+        // range of tiles so neighbours that share an activation tile share an L2.  Bijective form.
+        int bid;
+        {
+            const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         }
-        for (int r = tid / C4; r < BM; r += RPP) {
-            const int m = m0 + r;
-            if (m >= M) break;
-            f32x4 val = *reinterpret_cast<const f32x4*>(Cs + r * LDC + c4 * 4);
-            float* dst;
-            if (!direct) {
-                dst = p.ws + ((size_t)z * p.M + m) * p.Cout + n;
+        const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+        // per-thread staging rows
+        int a_iy0[AP], a_ix0[AP], a_pix[AP];
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int m = m0 + srow + 32 * i;
+            if (m < M) {
+                const int b = m / ohw;
+                const int rem = m - b * ohw;
+                const int oy = rem / p.OW;
+                const int ox = rem - oy * p.OW;
+                a_iy0[i] = oy * p.stride - p.pad;
+                a_ix0[i] = ox * p.stride - p.pad;
+                a_pix[i] = b * p.H * p.W;
             } else {
-                val += bias4;
-                if (p.out_mode == 0) {
-                    if (p.res_mode == 1) {
-                        val += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + n);
-                    } else if (p.res_mode == 2) {
+                a_iy0[i] = -(1 << 28);   // never valid
+                a_ix0[i] = 0;
+                a_pix[i] = 0;
+            }
+        }
+
+        f32x4 ra[KS][AP], rb[KS][BP];
+        auto load_step = [&](int sb) {
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+                int ss = sb * KS + u;
+                const bool live = ss < p.steps_total;       // odd tail of a KS = 2 schedule: A is zero-filled
+                ss = live ? ss : p.steps_total - 1;
+                const int r = ss / steps_per_row;
+                const int q = ((ss - r * steps_per_row) << 5) + (slot << 2);
+                const int dpx = q >> p.cin_log2;
+#pragma unroll
+                for (int i = 0; i < AP; ++i) {
+                    const int iy = a_iy0[i] + r;
+                    const int px = a_ix0[i] + dpx;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (live && (unsigned)iy < (unsigned)p.H && (unsigned)px < (unsigned)p.W) {
+                        const int off = ((a_pix[i] + iy * p.W + a_ix0[i]) << p.cin_log2) + q;
+                        v = *reinterpret_cast<const f32x4*>(p.x + off);
+                    }
+                    ra[u][i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < BP; ++i) {
+                    const int n = n0 + srow + 32 * i;
+                    rb[u][i] = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * w_row + (size_t)r * p.KWCp + q);
+                }
+            }
+        };
+        auto store_step = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+#pragma unroll
+                for (int i = 0; i < AP; ++i) {
+                    const int row = srow + 32 * i;
+                    const int ps = slot ^ ((row >> 1) & 7);
+                    *reinterpret_cast<f32x4*>(As + (buf * KS + u) * BM * 32 + row * 32 + ps * 4) = ra[u][i];
+                }
+#pragma unroll
+                for (int i = 0; i < BP; ++i) {
+                    const int row = srow + 32 * i;
+                    const int ps = slot ^ ((row >> 1) & 7);
+                    *reinterpret_cast<f32x4*>(Bs + (buf * KS + u) * BN * 32 + row * 32 + ps * 4) = rb[u][i];
+                }
+            }
+        };
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+        if (s_begin < s_end) {
+            load_step(s_begin);
+            store_step(0);
+            __syncthreads();
+            for (int sb = s_begin; sb < s_end; ++sb) {
+                const int buf = (sb - s_begin) & 1;
+                if (sb + 1 < s_end) load_step(sb + 1);
+                // fragments are double-buffered in registers: the ds_read_b128s of chunk c+1 are issued
+                // before the MFMAs of chunk c, so LDS latency hides behind the matrix pipe.
+                f32x4 af[2][TM], bf[2][TN];
+                auto load_frags = [&](int cc, int fb) {
+                    const int u = cc >> 2, c = cc & 3;
+                    const float* Ab = As + (buf * KS + u) * BM * 32;
+                    const float* Bb = Bs + (buf * KS + u) * BN * 32;
+                    const int ls = 2 * c + fh;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = (wm * TM + i) * 32 + fr;
+                        af[fb][i] = *reinterpret_cast<const f32x4*>(Ab + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int row = (wn * TN + j) * 32 + fr;
+                        bf[fb][j] = *reinterpret_cast<const f32x4*>(Bb + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
+                    }
+                };
+                load_frags(0, 0);
+#pragma unroll
+                for (int cc = 0; cc < 4 * KS; ++cc) {
+                    if (cc + 1 < 4 * KS) load_frags(cc + 1, (cc + 1) & 1);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cc & 1][i][k], bf[cc & 1][j][k], acc[i][j], 0, 0, 0);
+                }
+                if (sb + 1 < s_end) store_step(buf ^ 1);
+                __syncthreads();
+            }
+        }
+
+        // -------------------------------------------------------------- epilogue
+        // Accumulators -> LDS (C layout, padded rows) -> 16-byte vector stores: one thread handles whole
+        // float4 chunks of a row, so bias / residual / output move as dwordx4 and the per-element address
+        // arithmetic of the 32x32 C/D map (col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)) disappears.
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * fh;
+                    Cs[row * LDC + (wn * TN + j) * 32 + fr] = acc[i][j][v];
+                }
+        __syncthreads();
+        constexpr int C4 = BN / 4;                 // float4 chunks per tile row
+        constexpr int RPP = 256 / C4;              // rows covered per pass
+        const int c4 = tid % C4;
+        const int n = n0 + c4 * 4;
+        const int ld_out = direct ? p.y_ld : p.Cout;
+        bool vec_ok;
+        if (!direct) vec_ok = (p.Cout & 3) == 0;
+        else if (p.out_mode == 1) vec_ok = (p.cdec & 3) == 0;
+        else vec_ok = ((ld_out & 3) == 0) && ((p.y_coff & 3) == 0) && (p.y_coff + n + 4 <= ld_out);
+        if (n < p.Cout) {
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            int co = n, g = 0;
+            if (direct) {
+                if (p.out_mode == 1) { g = n / p.cdec; co = n - g * p.cdec; }
+                if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);     // bias is padded to Cout_p
+            }
+            for (int r = tid / C4; r < BM; r += RPP) {
+                const int m = m0 + r;
+                if (m >= M) break;
+                f32x4 val = *reinterpret_cast<const f32x4*>(Cs + r * LDC + c4 * 4);
+                float* dst;
+                if (!direct) {
+                    dst = p.ws + ((size_t)z * p.M + m) * p.Cout + n;
+                } else {
+                    val += bias4;
+                    if (p.out_mode == 0) {
+                        if (p.res_mode == 1) {
+                            val += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + n);
+                        } else if (p.res_mode == 2) {
+                            const int b = m / ohw;
+                            const int rem = m - b * ohw;
+                            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                            const int hw2 = (p.OH >> 1) * (p.OW >> 1);
+                            val += *reinterpret_cast<const f32x4*>(
+                                p.res + ((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n);
+                        }
+                        dst = p.y + (size_t)m * p.y_ld + p.y_coff + n;
+                    } else {
                         const int b = m / ohw;
                         const int rem = m - b * ohw;
                         const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                        const int hw2 = (p.OH >> 1) * (p.OW >> 1);
-                        val += *reinterpret_cast<const f32x4*>(
-                            p.res + ((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n);
+                        dst = p.y + (((size_t)b * 2 * p.OH + 2 * oy + (g >> 1)) * (2 * p.OW) + 2 * ox + (g & 1)) * p.cdec + co;
                     }
-                    dst = p.y + (size_t)m * p.y_ld + p.y_coff + n;
+                    if (p.relu) {
+                        val[0] = val[0] > 0.f ? val[0] : 0.f; val[1] = val[1] > 0.f ? val[1] : 0.f;
+                        val[2] = val[2] > 0.f ? val[2] : 0.f; val[3] = val[3] > 0.f ? val[3] : 0.f;
+                    }
+                }
+                if (vec_ok) {
+                    *reinterpret_cast<f32x4*>(dst) = val;
                 } else {
-                    const int b = m / ohw;
-                    const int rem = m - b * ohw;
-                    const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                    dst = p.y + (((size_t)b * 2 * p.OH + 2 * oy + (g >> 1)) * (2 * p.OW) + 2 * ox + (g & 1)) * p.cdec + co;
+                    for (int k = 0; k < 4; ++k) if (n + k < p.Cout) dst[k] = val[k];
                 }
-                if (p.relu) {
-                    val[0] = val[0] > 0.f ? val[0] : 0.f; val[1] = val[1] > 0.f ? val[1] : 0.f;
-                    val[2] = val[2] > 0.f ? val[2] : 0.f; val[3] = val[3] > 0.f ? val[3] : 0.f;
-                }
-            }
-            if (vec_ok) {
-                *reinterpret_cast<f32x4*>(dst) = val;
-            } else {
-                for (int k = 0; k < 4; ++k) if (n + k < p.Cout) dst[k] = val[k];
             }
         }
+        __syncthreads();       // Cs is overwritten by the next tile's staging
     }
 }
 
@@ -284,19 +301,20 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvParams p) {
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int KS>
 static int launch_cfg(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
-    const size_t lds_stage = (size_t)2 * (BM + BN) * 32 * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+    const size_t lds_stage = (size_t)2 * KS * (BM + BN) * 32 * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
     const size_t lds = lds_stage > lds_c ? lds_stage : lds_c;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, KS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN>), dim3(tiles, p.splitk), dim3(256), lds, s, p);
+    const int grid_x = (p.m_count && tiles > 1024) ? 1024 : tiles;
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, KS>), dim3(grid_x, p.splitk), dim3(256), lds, s, p);
     if (p.splitk > 1) {
         const size_t total = (size_t)p.M * p.Cout;
         int blocks = (int)((total + 255) / 256);
@@ -310,10 +328,10 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s) {
     if (p.M <= 0 || p.Cout <= 0 || p.steps_total <= 0) return APSE_E_INVALID;
     if (p.res_mode != 0 && (p.Cout & 3) != 0) return APSE_E_INVALID;      // residual rows are read as float4
     switch (cfg) {
-        case 0: return launch_cfg<2, 2, 2, 2>(p, s);
-        case 1: return launch_cfg<2, 2, 1, 1>(p, s);
-        case 2: return launch_cfg<4, 1, 1, 1>(p, s);
-        case 3: return launch_cfg<4, 1, 1, 2>(p, s);
+        case 0: return launch_cfg<2, 2, 2, 2, 1>(p, s);
+        case 1: return launch_cfg<2, 2, 1, 1, 2>(p, s);
+        case 2: return launch_cfg<4, 1, 1, 1, 2>(p, s);
+        case 3: return launch_cfg<4, 1, 1, 2, 1>(p, s);
         default: return APSE_E_INVALID;
     }
 }

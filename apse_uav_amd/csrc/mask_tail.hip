@@ -48,66 +48,71 @@ __global__ void det_postprocess(const PasteParams p, int n_max) {
 }
 
 #define PASTE_ROWSPLIT 16
-// grid (n_max, PASTE_ROWSPLIT), 256 threads = 4 waves; wave w of block c handles window rows
-// y0 + (c*4 + w) + k * 4*PASTE_ROWSPLIT.  A wave covers 64 pixels per step; ballot -> one word.
+// 1-D grid of PASTE_BLOCKS blocks striding over (detection, row-split) items of the LIVE detections
+// only; 256 threads = 4 waves; wave w of split c handles window rows y0 + (c*4 + w) + k*4*PASTE_ROWSPLIT.
+// A wave covers 64 pixels per step; ballot -> one 64-bit word of the bit plane.
+#define PASTE_BLOCKS 512
 __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_max) {
     __shared__ float prob[32 * 32];
     __shared__ unsigned long long red[4][3];
-    const int i = blockIdx.x;
-    if (i >= n_max || i >= *p.total) return;
-    if (!p.valid[i]) return;
-    const int M = p.M;
-    const int c = p.cls[i];
-    const float* lg = p.logits + (size_t)i * M * M * p.ldc + c;
-    for (int t = threadIdx.x; t < M * M; t += blockDim.x) prob[t] = 1.0f / (1.0f + expf(-lg[(size_t)t * p.ldc]));
-    __syncthreads();
+    const int total = *p.total < n_max ? *p.total : n_max;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rx0 = p.rect[i * 4 + 0], ry0 = p.rect[i * 4 + 1], rx1 = p.rect[i * 4 + 2], ry1 = p.rect[i * 4 + 3];
-    const float bx0 = p.boxes_out[i * 4 + 0], by0 = p.boxes_out[i * 4 + 1];
-    const float bx1 = p.boxes_out[i * 4 + 2], by1 = p.boxes_out[i * 4 + 3];
-    const float bw = bx1 - bx0, bh = by1 - by0;
-    const float Mf = (float)M;
-    uint64_t* bits = p.bits + (size_t)i * p.out_h * p.words_per_row;
-    unsigned long long mass = 0, sx = 0, sy = 0;
-    const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
-    for (int y = ry0 + blockIdx.y * 4 + wave; y < ry1; y += 4 * PASTE_ROWSPLIT) {
-        // normalised y, grid_sample unnormalise (align_corners=False)
-        const float gy = ((float)y + 0.5f - by0) / bh * 2.0f - 1.0f;
-        const float iy = ((gy + 1.0f) * Mf - 1.0f) / 2.0f;
-        const float fy = floorf(iy);
-        const int iy0 = (int)fy, iy1 = iy0 + 1;
-        const float wy1 = iy - fy, wy0 = 1.0f - wy1;   // torch CPU grid_sample: n = y - floor(y), s = 1 - n
-        const bool y0in = (unsigned)iy0 < (unsigned)M, y1in = (unsigned)iy1 < (unsigned)M;
-        for (int w = w0; w < w1; ++w) {
-            const int x = (w << 6) + lane;
-            bool on = false;
-            if (x >= rx0 && x < rx1) {
-                const float gx = ((float)x + 0.5f - bx0) / bw * 2.0f - 1.0f;
-                const float ix = ((gx + 1.0f) * Mf - 1.0f) / 2.0f;
-                const float fx = floorf(ix);
-                const int ix0 = (int)fx, ix1 = ix0 + 1;
-                const float wx1 = ix - fx, wx0 = 1.0f - wx1;
-                const bool x0in = (unsigned)ix0 < (unsigned)M, x1in = (unsigned)ix1 < (unsigned)M;
-                float v = 0.f;
-                if (y0in && x0in) v += prob[iy0 * M + ix0] * (wy0 * wx0);
-                if (y0in && x1in) v += prob[iy0 * M + ix1] * (wy0 * wx1);
-                if (y1in && x0in) v += prob[iy1 * M + ix0] * (wy1 * wx0);
-                if (y1in && x1in) v += prob[iy1 * M + ix1] * (wy1 * wx1);
-                on = v >= p.thresh;
+    for (int item = blockIdx.x; item < total * PASTE_ROWSPLIT; item += gridDim.x) {
+        const int i = item / PASTE_ROWSPLIT, split = item - i * PASTE_ROWSPLIT;
+        if (!p.valid[i]) continue;
+        const int M = p.M;
+        const int c = p.cls[i];
+        const float* lg = p.logits + (size_t)i * M * M * p.ldc + c;
+        __syncthreads();                    // previous item's prob/red readers are done
+        for (int t = threadIdx.x; t < M * M; t += blockDim.x) prob[t] = 1.0f / (1.0f + expf(-lg[(size_t)t * p.ldc]));
+        __syncthreads();
+        const int rx0 = p.rect[i * 4 + 0], ry0 = p.rect[i * 4 + 1], rx1 = p.rect[i * 4 + 2], ry1 = p.rect[i * 4 + 3];
+        const float bx0 = p.boxes_out[i * 4 + 0], by0 = p.boxes_out[i * 4 + 1];
+        const float bx1 = p.boxes_out[i * 4 + 2], by1 = p.boxes_out[i * 4 + 3];
+        const float bw = bx1 - bx0, bh = by1 - by0;
+        const float Mf = (float)M;
+        uint64_t* bits = p.bits + (size_t)i * p.out_h * p.words_per_row;
+        unsigned long long mass = 0, sx = 0, sy = 0;
+        const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
+        for (int y = ry0 + split * 4 + wave; y < ry1; y += 4 * PASTE_ROWSPLIT) {
+            // normalised y, grid_sample unnormalise (align_corners=False)
+            const float gy = ((float)y + 0.5f - by0) / bh * 2.0f - 1.0f;
+            const float iy = ((gy + 1.0f) * Mf - 1.0f) / 2.0f;
+            const float fy = floorf(iy);
+            const int iy0 = (int)fy, iy1 = iy0 + 1;
+            const float wy1 = iy - fy, wy0 = 1.0f - wy1;   // torch CPU grid_sample: n = y - floor(y), s = 1 - n
+            const bool y0in = (unsigned)iy0 < (unsigned)M, y1in = (unsigned)iy1 < (unsigned)M;
+            for (int w = w0; w < w1; ++w) {
+                const int x = (w << 6) + lane;
+                bool on = false;
+                if (x >= rx0 && x < rx1) {
+                    const float gx = ((float)x + 0.5f - bx0) / bw * 2.0f - 1.0f;
+                    const float ix = ((gx + 1.0f) * Mf - 1.0f) / 2.0f;
+                    const float fx = floorf(ix);
+                    const int ix0 = (int)fx, ix1 = ix0 + 1;
+                    const float wx1 = ix - fx, wx0 = 1.0f - wx1;
+                    const bool x0in = (unsigned)ix0 < (unsigned)M, x1in = (unsigned)ix1 < (unsigned)M;
+                    float v = 0.f;
+                    if (y0in && x0in) v += prob[iy0 * M + ix0] * (wy0 * wx0);
+                    if (y0in && x1in) v += prob[iy0 * M + ix1] * (wy0 * wx1);
+                    if (y1in && x0in) v += prob[iy1 * M + ix0] * (wy1 * wx0);
+                    if (y1in && x1in) v += prob[iy1 * M + ix1] * (wy1 * wx1);
+                    on = v >= p.thresh;
+                }
+                const uint64_t word = __ballot(on);
+                if (lane == 0) bits[(size_t)y * p.words_per_row + w] = word;
+                if (on) { mass += 1; sx += (unsigned long long)(x + 1); sy += (unsigned long long)(y + 1); }
             }
-            const uint64_t word = __ballot(on);
-            if (lane == 0) bits[(size_t)y * p.words_per_row + w] = word;
-            if (on) { mass += 1; sx += (unsigned long long)(x + 1); sy += (unsigned long long)(y + 1); }
         }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        mass += __shfl_xor(mass, o); sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o);
-    }
-    if (lane == 0) { red[wave][0] = mass; red[wave][1] = sx; red[wave][2] = sy; }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const unsigned long long t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (t) atomicAdd(p.sums + (size_t)i * 3 + threadIdx.x, t);
+        for (int o = 32; o > 0; o >>= 1) {
+            mass += __shfl_xor(mass, o); sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o);
+        }
+        if (lane == 0) { red[wave][0] = mass; red[wave][1] = sx; red[wave][2] = sy; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const unsigned long long t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            if (t) atomicAdd(p.sums + (size_t)i * 3 + threadIdx.x, t);
+        }
     }
 }
 
@@ -122,55 +127,58 @@ __global__ void mask_centroids(const unsigned long long* __restrict__ sums, cons
     cent[i * 2 + 1] = m ? (int)(sums[i * 3 + 2] / m) : -1;
 }
 
-// grid (n_max [mask i], kd [j-th detection of the same image]); closest[i][jl] = (x, y) 1-based, or (-1,-1).
+// 1-D grid striding over the pairs (mask i, jl-th detection of the same image) of the live list;
+// closest[i][jl] = (x, y) 1-based, or (-1,-1).
 __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict__ bits_all, const int* __restrict__ rect,
                                                       const int* __restrict__ valid, const int* __restrict__ cent,
                                                       const int* __restrict__ img, const int* __restrict__ offset,
                                                       const int* __restrict__ total, int kd, int out_h, int out_w,
                                                       int words_per_row, int* __restrict__ closest) {
     __shared__ unsigned long long best[4];
-    const int i = blockIdx.x, jl = blockIdx.y;
     const int n = *total;
-    if (i >= n) return;
-    const int j = offset[img[i]] + jl;
-    if (j >= offset[img[i] + 1]) return;
-    int* o = closest + ((size_t)i * kd + jl) * 2;
-    if (!valid[i] || cent[j * 2] < 0) {
-        if (threadIdx.x == 0) { o[0] = -1; o[1] = -1; }
-        return;
-    }
-    const float px = (float)cent[j * 2], py = (float)cent[j * 2 + 1];
-    const int rx0 = rect[i * 4 + 0], ry0 = rect[i * 4 + 1], rx1 = rect[i * 4 + 2], ry1 = rect[i * 4 + 3];
-    const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
-    const int nw = w1 - w0, nrows = ry1 - ry0;
-    const uint64_t* bits = bits_all + (size_t)i * out_h * words_per_row;
-    unsigned long long b = ~0ull;
-    for (int t = threadIdx.x; t < nw * nrows; t += blockDim.x) {
-        const int ry = t / nw, w = w0 + (t - ry * nw);
-        const int y = ry0 + ry;
-        uint64_t word = bits[(size_t)y * words_per_row + w];
-        const float dy = (float)(y + 1) - py;
-        const float dy2 = dy * dy;
-        while (word) {
-            const int bit = __ffsll((long long)word) - 1;
-            word &= word - 1;
-            const int x = (w << 6) + bit;
-            const float dx = (float)(x + 1) - px;
-            const float d = dx * dx + dy2;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(y * out_w + x);
-            b = key < b ? key : b;
+    for (int pair = blockIdx.x; pair < n * kd; pair += gridDim.x) {
+        const int i = pair / kd, jl = pair - i * kd;
+        const int j = offset[img[i]] + jl;
+        if (j >= offset[img[i] + 1]) continue;
+        int* o = closest + ((size_t)i * kd + jl) * 2;
+        if (!valid[i] || cent[j * 2] < 0) {
+            if (threadIdx.x == 0) { o[0] = -1; o[1] = -1; }
+            continue;
         }
-    }
-    for (int k = 32; k > 0; k >>= 1) { const unsigned long long other = __shfl_xor(b, k); b = other < b ? other : b; }
-    if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6] = b;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; ++k) b = best[k] < b ? best[k] : b;
-        if (b == ~0ull) { o[0] = -1; o[1] = -1; }
-        else {
-            const unsigned lin = (unsigned)(b & 0xffffffffu);
-            o[0] = (int)(lin % (unsigned)out_w) + 1;
-            o[1] = (int)(lin / (unsigned)out_w) + 1;
+        const float px = (float)cent[j * 2], py = (float)cent[j * 2 + 1];
+        const int rx0 = rect[i * 4 + 0], ry0 = rect[i * 4 + 1], rx1 = rect[i * 4 + 2], ry1 = rect[i * 4 + 3];
+        const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
+        const int nw = w1 - w0, nrows = ry1 - ry0;
+        const uint64_t* bits = bits_all + (size_t)i * out_h * words_per_row;
+        unsigned long long b = ~0ull;
+        for (int t = threadIdx.x; t < nw * nrows; t += blockDim.x) {
+            const int ry = t / nw, w = w0 + (t - ry * nw);
+            const int y = ry0 + ry;
+            uint64_t word = bits[(size_t)y * words_per_row + w];
+            const float dy = (float)(y + 1) - py;
+            const float dy2 = dy * dy;
+            while (word) {
+                const int bit = __ffsll((long long)word) - 1;
+                word &= word - 1;
+                const int x = (w << 6) + bit;
+                const float dx = (float)(x + 1) - px;
+                const float d = dx * dx + dy2;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(y * out_w + x);
+                b = key < b ? key : b;
+            }
+        }
+        for (int k = 32; k > 0; k >>= 1) { const unsigned long long other = __shfl_xor(b, k); b = other < b ? other : b; }
+        __syncthreads();                 // best[] of the previous pair has been consumed
+        if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6] = b;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; ++k) b = best[k] < b ? best[k] : b;
+            if (b == ~0ull) { o[0] = -1; o[1] = -1; }
+            else {
+                const unsigned lin = (unsigned)(b & 0xffffffffu);
+                o[0] = (int)(lin % (unsigned)out_w) + 1;
+                o[1] = (int)(lin / (unsigned)out_w) + 1;
+            }
         }
     }
 }
@@ -245,7 +253,7 @@ int apse_k_mask_paste(const PasteParams* p, int n_max, int* cent, int* mass, hip
     if (p->M > 32) return APSE_E_INVALID;
     hipMemsetAsync(p->sums, 0, (size_t)n_max * 3 * sizeof(unsigned long long), s);
     hipLaunchKernelGGL(det_postprocess, dim3((n_max + 63) / 64), dim3(64), 0, s, *p, n_max);
-    hipLaunchKernelGGL(paste_masks, dim3(n_max, PASTE_ROWSPLIT), dim3(256), 0, s, *p, n_max);
+    hipLaunchKernelGGL(paste_masks, dim3(PASTE_BLOCKS), dim3(256), 0, s, *p, n_max);
     hipLaunchKernelGGL(mask_centroids, dim3((n_max + 63) / 64), dim3(64), 0, s, p->sums, p->total, n_max, cent, mass);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
@@ -253,7 +261,7 @@ int apse_k_closest_points(const uint64_t* bits, const int* rect, const int* vali
                           const int* offset, const int* total, int n_max, int kd, int out_h, int out_w, int words_per_row,
                           int* closest, hipStream_t s) {
     if (n_max <= 0) return APSE_OK;
-    hipLaunchKernelGGL(closest_points, dim3(n_max, kd), dim3(256), 0, s, bits, rect, valid, cent, img, offset, total, kd, out_h,
+    hipLaunchKernelGGL(closest_points, dim3(n_max * kd < 1024 ? n_max * kd : 1024), dim3(256), 0, s, bits, rect, valid, cent, img, offset, total, kd, out_h,
                        out_w, words_per_row, closest);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }

@@ -23,10 +23,10 @@ __global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const flo
                                                       const int* __restrict__ total, int per_img, int n_max, int R,
                                                       float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
-    const int bin = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rr = R * R;
+    const int nlive = roi_img ? (*total < n_max ? *total : n_max) : n_max;
+    for (int bin = blockIdx.x * 4 + (threadIdx.x >> 6); bin < nlive * rr; bin += gridDim.x * 4) {
     const int r = bin / rr;
-    if (r >= n_max) return;
     const int pb = bin - r * rr;
     const int ph = pb / R, pw = pb - ph * R;
     int img;
@@ -40,9 +40,8 @@ __global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const flo
     }
     float* o = out + ((size_t)r * rr + pb) * 256 + lane * 4;
     if (!live) {
-        if (roi_img) return;             // packed list: rows past the count are never read
-        *reinterpret_cast<f32x4*>(o) = f32x4{0.f, 0.f, 0.f, 0.f};
-        return;
+        if (!roi_img) *reinterpret_cast<f32x4*>(o) = f32x4{0.f, 0.f, 0.f, 0.f};
+        continue;                         // packed list: rows past the count are never read
     }
     const float x1 = rois[r * 4 + 0], y1 = rois[r * 4 + 1], x2 = rois[r * 4 + 2], y2 = rois[r * 4 + 3];
     // assign_boxes_to_levels: floor(4 + log2(sqrt(area) / 224 + eps)), clamped to [2, 5]
@@ -83,6 +82,7 @@ __global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const flo
         }
     }
     *reinterpret_cast<f32x4*>(o) = acc / cntf;
+    }
 }
 
 // torchvision roi_pool forward on one NHWC map; rois in original-frame pixels, packed list.
@@ -91,10 +91,10 @@ __global__ __launch_bounds__(256) void roi_pool_nhwc(const float* __restrict__ f
                                                      const int* __restrict__ total, int n_max, int R, float scale,
                                                      float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
-    const int bin = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rr = R * R;
+    const int live = (*total < n_max ? *total : n_max) * rr;
+    for (int bin = blockIdx.x * 4 + (threadIdx.x >> 6); bin < live; bin += gridDim.x * 4) {
     const int r = bin / rr;
-    if (r >= n_max || r >= *total) return;
     const int pb = bin - r * rr;
     const int ph = pb / R, pw = pb - ph * R;
     const float* f = feat + (size_t)roi_img[r] * H * W * 256 + lane * 4;
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void roi_pool_nhwc(const float* __restrict__ f
             m[3] = v[3] > m[3] ? v[3] : m[3];
         }
     *reinterpret_cast<f32x4*>(out + ((size_t)r * rr + pb) * 256 + lane * 4) = m;
+    }
 }
 
 // F.normalize(x, p=2, dim=1, eps=1e-12) on [n][D] rows, one wave per row (D <= 256, D % 64 == 0 not required).
@@ -147,15 +148,17 @@ __global__ __launch_bounds__(64) void sqdist_matrix(const float* __restrict__ a,
 extern "C" {
 int apse_k_roi_align(const FpnMaps* F, const float* rois, const int* roi_img, const int* cnt, const int* total, int per_img,
                      int n_max, int R, float* out, hipStream_t s) {
-    const int bins = n_max * R * R;
-    hipLaunchKernelGGL(roi_align_nhwc, dim3((bins + 3) / 4), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R,
+    int blocks = (n_max * R * R + 3) / 4;
+    if (roi_img && blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(roi_align_nhwc, dim3(blocks), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R,
                        out);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_roi_pool(const float* feat, int H, int W, const float* rois, const int* roi_img, const int* total, int n_max,
                     int R, float scale, float* out, hipStream_t s) {
-    const int bins = n_max * R * R;
-    hipLaunchKernelGGL(roi_pool_nhwc, dim3((bins + 3) / 4), dim3(256), 0, s, feat, H, W, rois, roi_img, total, n_max, R, scale,
+    int blocks = (n_max * R * R + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(roi_pool_nhwc, dim3(blocks), dim3(256), 0, s, feat, H, W, rois, roi_img, total, n_max, R, scale,
                        out);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
