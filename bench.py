@@ -40,6 +40,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP-event timing (no roofline block)")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="HIP-event pairs around every convolution launch on every n-th timed step (each pair costs "
+                         "~5 us of stream time, ~1.5 ms per fully instrumented frame)")
+    ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--bg-bias", type=float, default=None)
     args = ap.parse_args()
 
@@ -104,7 +108,7 @@ def main():
     for i in range(args.warmup):
         res = step(i, False)
     torch.cuda.synchronize()
-    _lib.check(lib.apse_profile(model._ctx, 0 if args.no_events else 1), model._ctx, "apse_profile")
+    lib.apse_profile(model._ctx, 0)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -112,6 +116,8 @@ def main():
     P_sum = N_sum = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if not args.no_events:
+            lib.apse_profile(model._ctx, 1 if i % max(args.event_every, 1) == 0 else 0)
         ts = time.perf_counter()
         res = step(args.warmup + i, True)
         lat.append(time.perf_counter() - ts)
@@ -166,19 +172,20 @@ def main():
                          "whole_path_tflops": round(flops_frame * fps / world / 1e12, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, asd, host_frames, blocks, H, W, args.cpu_frames)
+            out["cpu_baseline"] = cpu_baseline(sd, asd, host_frames, blocks, H, W, args.cpu_frames, args.cpu_threads)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(sd, asd, host_frames, blocks, H, W, nframes):
+def cpu_baseline(sd, asd, host_frames, blocks, H, W, nframes, max_threads):
     """The CPU oracle (a port: the reference's own CPU path cannot run, detectron2 is absent) on the same
     frames and weights: PIL resize + detector + roi_pool/embedding + tracker association + CSV line."""
     from PIL import Image
     from oracle import tracker as otr
     from oracle.detector import DetectorOracle, resize_shape
-    ncores = torch.get_num_threads()
+    ncores = min(torch.get_num_threads(), max_threads, os.cpu_count() or 1)
+    torch.set_num_threads(ncores)
     oracle = DetectorOracle(sd, dict(depth_blocks=blocks))
     ih, iw = resize_shape(H, W)
     otk = otr.TrackerOracle()

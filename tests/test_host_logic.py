@@ -1,0 +1,168 @@
+"""CPU (-m "not gpu"): host-side logic of the product package and the C-ABI surface (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from apse_uav_amd import _lib
+    lib = _lib.load()
+    with open(os.path.join(ROOT, "include", "apse_hip.h")) as f:
+        text = f.read()
+    declared = set(re.findall(r"\b(apse_[a-z0-9_]+)\s*\(", text))
+    declared -= {"apse_ctx", "apse_config"}
+    assert len(declared) >= 35
+    for name in sorted(declared):
+        assert hasattr(lib, name), "missing export " + name
+    assert set(_lib.EXPORTS) <= declared
+    assert ctypes.sizeof(_lib.Config) == 25 * 4      # apse_config: 25 four-byte fields
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: creating a context without a HIP device must raise, not degrade."""
+    from apse_uav_amd import _lib
+    from apse_uav_amd.config import setup_cfg
+    from apse_uav_amd.networks.track_rcnn import TrackRCNN
+    from apse_uav_amd.weights import synthetic_detector_state
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = TrackRCNN(setup_cfg())
+    m.load_state_dict(synthetic_detector_state(0, (1, 1, 1, 1)))
+    with pytest.raises(_lib.ApseError):
+        m._ensure_ctx((270, 480), (252, 448))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "apse_uav_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py"):
+                with open(os.path.join(dirpath, fn)) as f:
+                    src = f.read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+
+
+def _det(n, frame=(100, 200)):
+    from apse_uav_amd.structures.instances import Boxes, Instances
+    from apse_uav_amd.structures.window_mask import MaskList, WindowMask
+    inst = Instances(frame)
+    inst.pred_boxes = Boxes(torch.arange(n * 4, dtype=torch.float32).view(n, 4))
+    inst.scores = torch.linspace(0.9, 0.6, n)
+    inst.pred_classes = torch.arange(n) % 4
+    inst.pred_masks = MaskList(WindowMask(None, (0, 0, 0, 0), frame, (k + 1, k + 2), 5) for k in range(n))
+    return inst
+
+
+def test_object_instances_semantics():
+    """object_instances.py: ids from 1, never reused; associate keeps the score; ageing and deletion."""
+    from apse_uav_amd.structures.object_instances import ObjectInstances
+    objs = ObjectInstances((100, 200))
+    d = _det(3)
+    emb = torch.eye(3, 128)
+    for k in range(3):
+        objs.add_new_object(k, d, emb)
+    assert objs.ids == [1, 2, 3] and len(objs) == 3
+    objs.finish_association()
+    assert objs.frames_since_detected == [0, 0, 0] and objs.detected_this_frame == [False] * 3
+    d2 = _det(2)
+    objs.associate_detection(1, 0, d2, torch.ones(2, 128))
+    assert objs.detected_this_frame == [True, False, False]
+    assert float(objs.scores[0]) == float(d.scores[0])                 # score frozen at first sighting
+    assert torch.equal(objs.pred_boxes[0].tensor, d2.pred_boxes[1].tensor)
+    rec = objs.get_recent_objects()
+    assert rec.ids == [1] and len(rec) == 1
+    objs.finish_association()
+    assert objs.frames_since_detected == [0, 1, 1]
+    objs._fields["frames_since_detected"] = [0, 101, 100]
+    objs.delete_undetected_objects(100)
+    assert objs.ids == [1, 3]
+    objs.add_new_object(0, d2, torch.ones(2, 128))
+    assert objs.ids == [1, 3, 4]                                        # 2 is never reused
+
+
+def test_csv_formats_and_consumer_roundtrip(tmp_path, golden_dir):
+    from apse_uav_amd.utils import csv_log
+    lines = ["0,1911.0,966.0,1911.0,966.0,192.0,1380.0,365.0,1338.0,3388.0,1020.0,3156.0,1014.0,269.0,498.0,468.0,543.0",
+             "1,1911.0,966.0,1911.0,966.0,,,,,3388.0,1020.0,3156.0,1014.0,269.0,498.0,468.0,543.0",
+             "2,1911.0,966.0,nan,nan,189.0,1389.0,nan,nan"]
+    raw = tmp_path / "raw.csv"
+    csv_log.write_raw_csv(str(raw), lines, 1, 4)
+    txt = raw.read_text().split("\n")
+    assert txt[0] == "Ford id: 1" and txt[1].startswith("frame,id_1 cent_x,id_1 cent_y,id_1 clos_x,id_1 clos_y,id_2 cent_x")
+    out = tmp_path / "consumer.csv"
+    csv_log.write_consumer_csv(str(out), lines, host_id=2, vehicle_ids=[4, 1, 3])
+    got = out.read_text()
+    with open(os.path.join(golden_dir, "static_dcnn_data_head.csv")) as f:
+        ref = f.read().split("\n")
+    g = got.split("\n")
+    assert g[0] == ref[0] and g[1] == ref[1]                           # shipped header lines, byte for byte
+    assert got.endswith("\n") and all(len(r.split(",")) == 17 for r in g[:-1])
+    data = csv_log.read_centroid_data(str(out))
+    assert data[0] == [0, 192, 1380, 365, 1338, 269, 498, 468, 543, 1911, 966, 1911, 966, 3388, 1020, 3156, 1014]
+    assert data[1][1:5] == [0, 0, 0, 0]                                 # blank cells -> 0 like readCentroidData
+    for name in ("static", "dynamic"):
+        ref_rows = csv_log.read_centroid_data(os.path.join(golden_dir, name + "_dcnn_data_head.csv"))
+        assert all(len(r) == 17 for r in ref_rows) and len(ref_rows) >= 5
+
+
+def test_log_line_matches_reference_shape():
+    from apse_uav_amd.structures.object_instances import ObjectInstances
+    from apse_uav_amd.utils import csv_log
+    objs = ObjectInstances((100, 200))
+    d = _det(3)
+    for k in range(3):
+        objs.add_new_object(k, d, torch.eye(3, 128))
+    objs.delete_undetected_objects(100)
+    rec = objs.get_recent_objects()
+    line, hi = csv_log.generate_log_oneline(rec, 2, 7, closest_lookup=lambda k, h: (10.0 + k, 20.0 + h))
+    assert hi == 3
+    assert line == "7,1.0,2.0,10.0,21.0,2.0,3.0,11.0,21.0,3.0,4.0,12.0,21.0"
+    line, _ = csv_log.generate_log_oneline(rec, 9, 8, closest_lookup=lambda k, h: (0.0, 0.0))
+    assert line == "8,1.0,2.0,nan,nan,2.0,3.0,nan,nan,3.0,4.0,nan,nan"
+
+
+def test_config_matches_reference_yaml_values():
+    from apse_uav_amd.config import get_cfg, setup_cfg
+    cfg = setup_cfg()
+    assert cfg.MODEL.ROI_HEADS.NUM_CLASSES == 4 and cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST == 0.5
+    assert cfg.MODEL.RPN.PRE_NMS_TOPK_TEST == 1000 and cfg.MODEL.RPN.POST_NMS_TOPK_TEST == 1000
+    assert cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION == 7 and cfg.MODEL.ROI_MASK_HEAD.POOLER_RESOLUTION == 14
+    assert tuple(cfg.MODEL.ROI_HEADS.IN_FEATURES) == ("p2", "p3", "p4", "p5")
+    c2 = cfg.clone()
+    c2.freeze()
+    with pytest.raises(AttributeError):
+        c2.MODEL.DEVICE = "cpu"
+    assert get_cfg().INPUT.MIN_SIZE_TEST == 800
+
+
+def test_window_mask_dense_roundtrip():
+    from apse_uav_amd.structures.window_mask import WindowMask
+    rng = np.random.default_rng(0)
+    H, W = 120, 300
+    x0, y0, x1, y1 = 70, 10, 205, 50
+    win = rng.random((y1 - y0, x1 - x0)) > 0.5
+    w0, w1 = x0 >> 6, (x1 + 63) >> 6
+    bits = np.zeros((y1 - y0, w1 - w0), np.uint64)
+    for yy in range(y1 - y0):
+        for xx in range(x1 - x0):
+            if win[yy, xx]:
+                X = x0 + xx
+                bits[yy, (X >> 6) - w0] |= np.uint64(1) << np.uint64(X & 63)
+    m = WindowMask(torch.from_numpy(bits.view(np.int64)), (x0, y0, x1, y1), (H, W), (1, 1), int(win.sum()))
+    dense = m.dense().numpy()
+    assert dense[y0:y1, x0:x1].tolist() == win.tolist() and dense.sum() == win.sum()
+
+
+def test_synthetic_sequence_deterministic():
+    from apse_uav_amd.synthetic import SyntheticSequence
+    a = SyntheticSequence("dynamic", 108, 192).frame(3)
+    b = SyntheticSequence("dynamic", 108, 192).frame(3)
+    assert a.dtype == np.uint8 and a.shape == (108, 192, 3) and np.array_equal(a, b)
+    s = SyntheticSequence("dynamic", 108, 192)
+    assert len(s.boxes(0)) == 4 and len(s.boxes(25)) == 3
