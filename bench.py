@@ -114,10 +114,13 @@ def main():
     torch.cuda.synchronize()
     lat = []
     P_sum = N_sum = 0
+    n_instr = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         if not args.no_events:
-            lib.apse_profile(model._ctx, 1 if i % max(args.event_every, 1) == 0 else 0)
+            on = i % max(args.event_every, 1) == 0
+            n_instr += int(on)
+            lib.apse_profile(model._ctx, 1 if on else 0)
         ts = time.perf_counter()
         res = step(args.warmup + i, True)
         lat.append(time.perf_counter() - ts)
@@ -168,7 +171,7 @@ def main():
                          "all_kernels": {CFG_NAMES[k]: {"ms": round(float(prof[k, 0]), 3),
                                                         "tflops": round(float(prof[k, 1] / max(prof[k, 0], 1e-9) / 1e9), 3),
                                                         "launches": int(prof[k, 2])} for k in range(4)},
-                         "conv_ms_per_frame": round(total_conv_ms / max(args.steps * B, 1), 3),
+                         "conv_ms_per_frame": round(total_conv_ms / max(n_instr * B, 1), 3), "instrumented_steps": n_instr,
                          "whole_path_tflops": round(flops_frame * fps / world / 1e12, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
