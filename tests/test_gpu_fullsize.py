@@ -1,0 +1,132 @@
+"""-m gpu: BASELINE.json full-size configuration (3840x2160 frames, R-101-FPN, f32) on the HIP path.
+
+* one frame against the CPU oracle (features, proposals, detections, masks, embeddings);
+* size-independent properties: determinism (same frame twice -> identical results block), batch 2 ==
+  2 x batch 1 per image, given-boxes mode CSV through the consumer's parser (config 1/2 plumbing).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+FRAME = (2160, 3840)
+
+
+def _log(logdir, name, obj):
+    with open(os.path.join(logdir, "fullsize_parity.log"), "a") as f:
+        f.write(name + " " + json.dumps(obj) + "\n")
+
+
+@pytest.fixture(scope="module")
+def env():
+    from apse_uav_amd.config import setup_cfg
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from apse_uav_amd.synthetic import SyntheticSequence
+    from apse_uav_amd.weights import UAV4K_R101_CLS_BIAS, synthetic_association_state, synthetic_detector_state
+    sd = synthetic_detector_state(0, cls_bias=UAV4K_R101_CLS_BIAS)
+    asd = synthetic_association_state(1)
+    cfg = setup_cfg()
+    cfg.APSE.MAX_BATCH = 2
+    tr = RcnnTracker(cfg, FRAME, asd, detector_state=sd)
+    seq = SyntheticSequence("dynamic", *FRAME)
+    return dict(sd=sd, asd=asd, cfg=cfg, tr=tr, seq=seq)
+
+
+def test_full_frame_vs_oracle(env, logdir):
+    from PIL import Image
+    from oracle import tracker as otr
+    from oracle.detector import DetectorOracle, resize_shape
+    tr = env["tr"]
+    frame = env["seq"].frame(0)
+    pred, feats = tr.predictor(frame)
+    inst = pred["instances"]
+    ih, iw = resize_shape(*FRAME)
+    assert (ih, iw) == (750, 1333)
+    img = np.asarray(Image.fromarray(frame).resize((iw, ih), Image.BILINEAR))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    post = DetectorOracle(env["sd"]).inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), *FRAME)
+    for k in ("p2", "p4", "p6"):
+        got, ref = feats[k].cpu(), post["features"][k]
+        d = float((got - ref).abs().max() / ref.abs().max())
+        _log(logdir, "feat/" + k, dict(rel=d))
+        assert d < 2e-4                                   # f32 through 104 convolutions, different sum order
+    model = tr.predictor.model
+    P = int(model.last_results.prop_count[0])
+    ref_props = post["proposals"]["boxes"]
+    props = model.debug_tensor("proposals").cpu().view(-1, 4)[:P]
+    same_p = int((props - ref_props[:P]).abs().max(dim=1).values.lt(0.05).sum()) if P == ref_props.shape[0] else -1
+    _log(logdir, "rpn", dict(P=P, ref_P=int(ref_props.shape[0]), rows_equal=same_p))
+    assert P == ref_props.shape[0]
+    assert same_p >= P - 20                               # near-tied logits at rank ~1000 may swap a few rows
+    n = len(inst)
+    _log(logdir, "dets", dict(n=n, ref_n=int(post["boxes"].shape[0]), scores=[round(float(s), 5) for s in inst.scores],
+                              ref=[round(float(s), 5) for s in post["scores"]]))
+    assert n == post["boxes"].shape[0]
+    assert torch.equal(inst.pred_classes, post["classes"])
+    assert float((inst.pred_boxes.tensor - post["boxes"]).abs().max()) < 0.1        # 4K frame pixels
+    assert float((inst.scores - post["scores"]).abs().max()) < 1e-4
+    bad = tot = 0
+    for k in range(n):
+        m = inst.pred_masks[k]
+        assert tuple(m.rect) == tuple(post["mask_rects"][k])
+        bad += int((m.window().cpu() != post["mask_windows"][k]).sum())
+        tot += int(m.mass)
+    _log(logdir, "masks", dict(mismatched=bad, total=tot))
+    assert bad <= max(8, tot // 20000)
+    if n:
+        rois = otr.features_rois(post["features"]["p2"], post["boxes"], FRAME[1])
+        emb = otr.association_head(rois, env["asd"]["fc.weight"], env["asd"]["fc.bias"])
+        de = float((torch.from_numpy(inst._record["embeddings"]) - emb).abs().max())
+        _log(logdir, "emb", dict(max_abs=de))
+        assert de < 2e-3
+
+
+def test_determinism_and_batch_equivalence(env):
+    tr = env["tr"]
+    pr = tr.predictor
+    f0, f1 = env["seq"].frame(0), env["seq"].frame(5)
+    a = pr.predict_batch([f0], want_masks=False)[0][0]["instances"]
+    b = pr.predict_batch([f0], want_masks=False)[0][0]["instances"]
+    assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and np.array_equal(a._record["embeddings"], b._record["embeddings"])
+    c = pr.predict_batch([f1], want_masks=False)[0][0]["instances"]
+    two = pr.predict_batch([f0, f1], want_masks=False)[0]
+    for one, bt in ((a, two[0]["instances"]), (c, two[1]["instances"])):
+        assert torch.equal(one.pred_boxes.tensor, bt.pred_boxes.tensor)
+        assert torch.equal(one.pred_classes, bt.pred_classes)
+        assert np.array_equal(one._record["centroids"], bt._record["centroids"])
+        assert np.array_equal(one._record["closest"], bt._record["closest"])
+        assert np.allclose(one._record["embeddings"], bt._record["embeddings"], atol=1e-6)
+
+
+def test_given_boxes_csv_roundtrip(env, tmp_path):
+    """Configs 1/2 plumbing: the K synthetic vehicles as given boxes -> tracker -> consumer CSV ->
+    aruco_detect.readCentroidData-style parse; centroids must fall inside their boxes."""
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from apse_uav_amd.utils import csv_log, resample
+    tr = RcnnTracker(env["cfg"], FRAME, env["asd"], detector_state=env["sd"])
+    seq = env["seq"]
+    ih, iw = resample.resize_shortest_edge(*FRAME)
+    sx, sy = iw / FRAME[1], ih / FRAME[0]
+    lines = []
+    for t in (0, 1, 2, 22):
+        boxes = seq.boxes(t) * np.array([sx, sy, sx, sy], np.float32)
+        given = (boxes, np.zeros(len(boxes), np.int32), np.array([len(boxes)], np.int32))
+        out = tr.predictor.predict_batch([seq.frame(t)], given=given)[0][0]["instances"]
+        assert len(out) == len(boxes)
+        tr.frame_count += 1
+        objs = tr._finish_frame(out, None)
+        line, hi = tr.log_line(objs, 1, t)
+        lines.append(line)
+        for k in range(len(out)):
+            cx, cy = out.pred_masks[k].centroid
+            x0, y0, x1, y1 = out.pred_boxes.tensor[k].tolist()
+            if out.pred_masks[k].mass:
+                assert x0 - 2 <= cx <= x1 + 2 and y0 - 2 <= cy <= y1 + 2
+    path = tmp_path / "seq_dcnn_data.csv"
+    csv_log.write_consumer_csv(str(path), lines, host_id=1, vehicle_ids=[2, 3, 4])
+    data = csv_log.read_centroid_data(str(path))
+    assert len(data) == 4 and all(len(r) == 17 for r in data)
+    assert data[0][0] == 0 and data[3][0] == 22
