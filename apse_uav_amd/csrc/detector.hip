@@ -49,6 +49,8 @@ int apse_k_mask_paste(const PasteParams*, int, int*, int*, hipStream_t);
 int apse_k_closest_points(const uint64_t*, const int*, const int*, const int*, const int*, const int*, const int*, int, int,
                           int, int, int, int*, hipStream_t);
 int apse_k_closest_single(const uint64_t*, int, int, int, float, float, unsigned long long*, hipStream_t);
+struct UndistortParams { double ir[9]; double k[12]; double fx, fy, u0, v0; int H, W; int do_undistort, do_gamma; };
+int apse_k_undistort_gamma(const UndistortParams*, const uint8_t*, uint8_t*, const uint8_t*, int, hipStream_t);
 int apse_k_bits_to_dense(const uint64_t*, const int*, int, int, int, uint8_t*, hipStream_t);
 int apse_k_dense_to_bits(const uint8_t*, int, int, int, uint64_t*, unsigned long long*, hipStream_t);
 }
@@ -1097,6 +1099,25 @@ int apse_l2_normalize(const float* x, float* y, int n, int D, void* stream) {
 }
 int apse_sqdist(const float* a, const float* b, int O, int N, int D, float* out, void* stream) {
     return apse_k_sqdist(a, b, O, N, D, out, (hipStream_t)stream);
+}
+int apse_undistort_gamma(const uint8_t* src, uint8_t* dst, int B, int H, int W, const double* m, const double* dist, int ndist,
+                         const uint8_t* lut, int do_undistort, int do_gamma, void* stream) {
+    if (!src || !dst || !m || ndist > 14 || (do_gamma && !lut)) return APSE_E_INVALID;
+    UndistortParams p;
+    memset(&p, 0, sizeof p);
+    for (int i = 0; i < ndist && i < 12; ++i) p.k[i] = dist[i];
+    if (ndist > 12 && (dist[12] != 0.0 || (ndist > 13 && dist[13] != 0.0))) return APSE_E_INVALID;   // tilt model not built
+    // inverse of the 3x3 camera matrix (double, adjugate / determinant)
+    const double a = m[0], b = m[1], c = m[2], dd = m[3], e = m[4], f = m[5], g = m[6], h = m[7], k = m[8];
+    const double det = a * (e * k - f * h) - b * (dd * k - f * g) + c * (dd * h - e * g);
+    if (det == 0.0) return APSE_E_INVALID;
+    const double id = 1.0 / det;
+    p.ir[0] = (e * k - f * h) * id; p.ir[1] = (c * h - b * k) * id; p.ir[2] = (b * f - c * e) * id;
+    p.ir[3] = (f * g - dd * k) * id; p.ir[4] = (a * k - c * g) * id; p.ir[5] = (c * dd - a * f) * id;
+    p.ir[6] = (dd * h - e * g) * id; p.ir[7] = (b * g - a * h) * id; p.ir[8] = (a * e - b * dd) * id;
+    p.fx = m[0]; p.fy = m[4]; p.u0 = m[2]; p.v0 = m[5];
+    p.H = H; p.W = W; p.do_undistort = do_undistort; p.do_gamma = do_gamma;
+    return apse_k_undistort_gamma(&p, src, dst, lut, B, (hipStream_t)stream);
 }
 int apse_resize_normalize(const uint8_t* frames, uint8_t* tmp, float* out, uint8_t* resized, const int* hb, const int* hc, int hk,
                           const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,

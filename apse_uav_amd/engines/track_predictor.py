@@ -27,6 +27,12 @@ class TrackPredictor:
         self.input_format = cfg.INPUT.FORMAT
         assert self.input_format in ["RGB", "BGR"], self.input_format
         self._staging = None
+        self.frame_preprocessor = None        # optional FramePreprocessor (cfg.APSE.FUSED_PREPROC / set_camera)
+
+    def set_camera(self, cam_params, gamma=2.0):
+        """Enables undistort + Lab-gamma in front of the resize (preprocess_img, visualize_uav.py:56-71)."""
+        from ..utils.preprocess import FramePreprocessor
+        self.frame_preprocessor = FramePreprocessor(cam_params, gamma)
 
     def _upload(self, frames):
         """list of HxWx3 uint8 arrays -> CUDA tensor [B, H, W, 3] through a pinned staging buffer."""
@@ -38,7 +44,10 @@ class TrackPredictor:
             if self.input_format == "RGB":
                 f = f[:, :, ::-1]
             self._staging[i].copy_(torch.from_numpy(np.ascontiguousarray(f)))
-        return self._staging.to(self.model.device, non_blocking=True)
+        dev = self._staging.to(self.model.device, non_blocking=True)
+        if self.frame_preprocessor is not None:
+            dev = self.frame_preprocessor(dev)
+        return dev
 
     def __call__(self, original_image):
         with torch.no_grad():

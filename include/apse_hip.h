@@ -170,6 +170,12 @@ int apse_mask_closest_dense(const uint8_t* mask_dev, int H, int W, float px, flo
 int apse_l2_normalize(const float* x_dev, float* y_dev, int n, int D, void* stream);
 int apse_sqdist(const float* a_dev, const float* b_dev, int O, int N, int D, float* out_dev, void* stream);
 /* PIL resize + normalise as a stand-alone op (tables as in apse_set_resize_tables, device pointers). */
+/* preprocess_img (visualize_uav.py:56-71): cv2.undistort + Lab-L gamma on u8 BGR frames [B][H][W][3].
+ * mtx3x3 row-major, dist up to 14 coefficients (k1 k2 p1 p2 k3 k4 k5 k6 s1..s4 tx ty; tilt must be 0),
+ * lut256_dev = the 256-entry L-channel table on the device.  Either stage can be disabled. */
+int apse_undistort_gamma(const uint8_t* src_dev, uint8_t* dst_dev, int B, int H, int W, const double* mtx3x3_host,
+                         const double* dist_host, int ndist, const uint8_t* lut256_dev, int do_undistort, int do_gamma,
+                         void* stream);
 int apse_resize_normalize(const uint8_t* frames_dev, uint8_t* tmp_dev, float* out_nhwc4_dev, uint8_t* resized_u8_dev,
                           const int* hb_dev, const int* hc_dev, int hk, const int* vb_dev, const int* vc_dev, int vk, int B,
                           int H, int W, int OH, int OW, int PH, int PW, const float* mean3_host, void* stream);
