@@ -336,22 +336,32 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s) {
     }
 }
 
-// Tile/split heuristic: fill >= ~1 wave of the 256 CUs; prefer the largest tile that does.
+// Tile/split heuristic (tools/conv_sweep.py on MI355X): fill >= ~2 resident blocks per CU; prefer the
+// largest tile that does; for small-M layers trade tile size against split-K:
+//   large K   -> 128x128 tiles with the K range split across blocks (fc1, res4/res5 3x3),
+//   medium K  -> 64x64 tiles (unsplit once there are >= 192 of them),
+//   tiny K, wide N (res4 conv3) -> 128x64 tiles.
 int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk) {
     *splitk = 1;
     auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
+    auto split_for = [&](int t, int min_steps_per_split) {
+        int sk = (512 + t / 2) / t;
+        if (sk > steps / min_steps_per_split) sk = steps / min_steps_per_split;
+        if (sk > 64) sk = 64;
+        return sk < 1 ? 1 : sk;
+    };
     if (Cout <= 32) return 2;
     if (Cout <= 64) return tiles(128, 64) >= 192 ? 3 : 1;
-    if (tiles(128, 128) >= 224) return 0;
-    // 64x64 tiles: aim for >= 2 resident blocks per CU (each block is one wave per SIMD, so a second
-    // block is what hides the per-step barrier and LDS latency); split K across blocks to get there.
-    int t = tiles(64, 64);
-    if (t < 384 && steps >= 16) {
-        int sk = (512 + t / 2) / t;
-        if (sk > steps / 4) sk = steps / 4;
-        if (sk > 64) sk = 64;
-        if (sk < 1) sk = 1;
-        *splitk = sk;
+    const int t128 = tiles(128, 128);
+    if (t128 >= 224) {
+        if (t128 < 384 && steps <= 16 && tiles(128, 64) >= 384) return 3;
+        return 0;
     }
+    if (t128 >= 32 && steps >= 64) {
+        *splitk = split_for(t128, 8);
+        return 0;
+    }
+    const int t64 = tiles(64, 64);
+    if (t64 < 192 && steps >= 16) *splitk = split_for(t64, 4);
     return 1;
 }
