@@ -39,10 +39,13 @@ struct ConvParams {
     int cdec;
     int splitk;           // >= 1
     int steps_total;      // KH * KWCp/32
+    int prec;             // 0: exact f32 MFMA; 1: operands rounded to bf16 at LDS staging, f32 accumulate (f32 storage)
 };
 
 int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s);   // cfg: 0=128x128 1=64x64 2=128x32 3=128x64
 int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk);
+int apse_launch_conv_bf16(const ConvParams& p, int cfg, hipStream_t s);   // conv_igemm_bf16.hip
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------- small helpers
 static inline int apse_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }

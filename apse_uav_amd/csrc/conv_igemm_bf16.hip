@@ -1,34 +1,25 @@
-// Implicit-GEMM convolution for gfx950 (CDNA4), exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+// Implicit-GEMM convolution, bf16 matrix cores (v_mfma_f32_32x32x16_bf16) with f32 storage (gfx950).
 //
-// Replaces, on the reference's path, every cuDNN/cuBLAS contraction reached through
-// detectron2's backbone / FPN / RPN head / box head / mask head and the association FC
-// (/root/reference/dcnn/networks/track_rcnn.py:42-51, dcnn/networks/association_head.py:23).
-//
-// GEMM view:  D[m][n] = sum_k A[m][k] * Wt[n][k]
-//   m = (b, oy, ox) output pixel, n = output channel, k = (r, q) with q running over the
-//   contiguous NHWC run of KW pixels x Cin channels of filter row r (so one k-step of 32 floats
-//   is one 128-byte contiguous read per output pixel; out-of-image pixels are zero-filled).
-// Block = 256 threads = 4 waves (one per SIMD); wave tile = TM x TN MFMA tiles of 32x32.
-// LDS: A and B k-slices [rows][32 f32] double-buffered, 16-byte slots XOR-swizzled with
-// (row>>1)&7 so both the ds_write_b128 staging and the ds_read_b128 fragment reads are
-// bank-conflict-free (MI355X_MICROARCH.md, LDS table: b128 reads are served per 16-lane group
-// over 64 banks).  One ds_read_b128 feeds FOUR MFMA k-steps: lane half h takes k = 8c+4h+j for
-// step j (the k order inside a chunk is a free choice as long as A and B agree).
-// Global->LDS staging goes through two register sets: the loads of k-step s+2 are issued before
-// the MFMAs of step s and written to LDS after the MFMAs of step s+1 (an f32 MFMA k-step is
-// 1024 cycles/wave at 64x64 and 4096 at 128x128); one barrier per k-step.
+// Same GEMM view, tiling, LDS swizzle, persistent tile loop, split-K and fused epilogue as
+// conv_igemm.hip; the difference is the operand precision: activations and filters are read as f32
+// from HBM, rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) while being staged into LDS,
+// multiplied on the bf16 MFMA (16x the f32 matrix rate) and accumulated / stored in f32.  An LDS row is
+// 64 bf16 = 128 bytes, so the 16-byte-slot XOR swizzle and the fragment addressing are unchanged: one
+// ds_read_b128 is exactly the 8 k-values a lane feeds to one 32x32x16 MFMA (k = 8*(lane>>5) + j).
+// Used for BASELINE configs 3/5 (cfg.APSE.DTYPE = "bf16"); decision layers (RPN logits/deltas, box
+// predictor, mask logits, association FC) stay on the exact-f32 kernel.
 #include "apse_common.h"
 
 template <int WM, int WN, int TM, int TN, int KS>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
+__global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int AP = BM / 32;   // staging passes (32 rows x 8 slots of 16 B per pass)
     constexpr int BP = BN / 32;
     constexpr int LDC = BN + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* As = reinterpret_cast<float*>(smem);   // [2][KS][BM*32]
-    float* Bs = As + 2 * KS * BM * 32;            // [2][KS][BN*32]
+    char* As = smem;                              // [2][KS][BM][64 bf16]  (128-byte rows, 16-byte slots)
+    char* Bs = As + 2 * KS * BM * 128;            // [2][KS][BN][64 bf16]
     float* Cs = reinterpret_cast<float*>(smem);   // epilogue view [BM][LDC]
 
     const int tid = threadIdx.x;
@@ -49,11 +40,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     const int z = blockIdx.y;
     // a "step" is KS sub-steps of 32 k each between two barriers (KS = 2 for the small tiles, whose
     // 1024-cycle MFMA sub-step is too short to cover an L2/HBM round trip)
-    const int steps_big = (p.steps_total + KS - 1) / KS;
+    // sub-steps of 64 k here (p.steps_total counts 32-k units of the padded run)
+    const int spr64 = (p.KWCp + 63) >> 6;
+    const int steps64 = p.KH * spr64;
+    const int steps_big = (steps64 + KS - 1) / KS;
     const int per = (steps_big + p.splitk - 1) / p.splitk;
     const int s_begin = z * per;
     const int s_end = (s_begin + per < steps_big) ? s_begin + per : steps_big;
-    const int steps_per_row = p.KWCp >> 5;
     const int ohw = p.OH * p.OW;
     const size_t w_row = (size_t)p.KH * p.KWCp;
     const bool direct = (p.splitk == 1);
@@ -91,31 +84,42 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
             }
         }
 
-        f32x4 ra[KS][AP], rb[KS][BP];
+        bf16x8 ra[KS][AP], rb[KS][BP];
+        auto cvt8 = [](const f32x4 lo, const f32x4 hi) {
+            bf16x8 r;
+            r[0] = (__bf16)lo[0]; r[1] = (__bf16)lo[1]; r[2] = (__bf16)lo[2]; r[3] = (__bf16)lo[3];
+            r[4] = (__bf16)hi[0]; r[5] = (__bf16)hi[1]; r[6] = (__bf16)hi[2]; r[7] = (__bf16)hi[3];
+            return r;
+        };
         auto load_step = [&](int sb) {
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
                 int ss = sb * KS + u;
-                const bool live = ss < p.steps_total;       // odd tail of a KS = 2 schedule: A is zero-filled
-                ss = live ? ss : p.steps_total - 1;
-                const int r = ss / steps_per_row;
-                const int q = ((ss - r * steps_per_row) << 5) + (slot << 2);
-                const int dpx = q >> p.cin_log2;
+                const bool live = ss < steps64;
+                ss = live ? ss : steps64 - 1;
+                const int r = ss / spr64;
+                const int q = ((ss - r * spr64) << 6) + (slot << 3);       // 8 consecutive k per thread
+                const bool qa = live && q < p.KWCp, qb = live && (q + 4) < p.KWCp;
+                const int dpa = q >> p.cin_log2, dpb = (q + 4) >> p.cin_log2;
 #pragma unroll
                 for (int i = 0; i < AP; ++i) {
                     const int iy = a_iy0[i] + r;
-                    const int px = a_ix0[i] + dpx;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (live && (unsigned)iy < (unsigned)p.H && (unsigned)px < (unsigned)p.W) {
+                    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+                    if ((unsigned)iy < (unsigned)p.H) {
                         const int off = ((a_pix[i] + iy * p.W + a_ix0[i]) << p.cin_log2) + q;
-                        v = *reinterpret_cast<const f32x4*>(p.x + off);
+                        if (qa && (unsigned)(a_ix0[i] + dpa) < (unsigned)p.W) lo = *reinterpret_cast<const f32x4*>(p.x + off);
+                        if (qb && (unsigned)(a_ix0[i] + dpb) < (unsigned)p.W) hi = *reinterpret_cast<const f32x4*>(p.x + off + 4);
                     }
-                    ra[u][i] = v;
+                    ra[u][i] = cvt8(lo, hi);
                 }
 #pragma unroll
                 for (int i = 0; i < BP; ++i) {
                     const int n = n0 + srow + 32 * i;
-                    rb[u][i] = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * w_row + (size_t)r * p.KWCp + q);
+                    const float* wp = p.w + (size_t)n * w_row + (size_t)r * p.KWCp + q;
+                    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+                    if (qa) lo = *reinterpret_cast<const f32x4*>(wp);
+                    if (qb) hi = *reinterpret_cast<const f32x4*>(wp + 4);
+                    rb[u][i] = cvt8(lo, hi);
                 }
             }
         };
@@ -126,13 +130,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
                 for (int i = 0; i < AP; ++i) {
                     const int row = srow + 32 * i;
                     const int ps = slot ^ ((row >> 1) & 7);
-                    *reinterpret_cast<f32x4*>(As + (buf * KS + u) * BM * 32 + row * 32 + ps * 4) = ra[u][i];
+                    *reinterpret_cast<bf16x8*>(As + ((buf * KS + u) * BM + row) * 128 + ps * 16) = ra[u][i];
                 }
 #pragma unroll
                 for (int i = 0; i < BP; ++i) {
                     const int row = srow + 32 * i;
                     const int ps = slot ^ ((row >> 1) & 7);
-                    *reinterpret_cast<f32x4*>(Bs + (buf * KS + u) * BN * 32 + row * 32 + ps * 4) = rb[u][i];
+                    *reinterpret_cast<bf16x8*>(Bs + ((buf * KS + u) * BN + row) * 128 + ps * 16) = rb[u][i];
                 }
             }
         };
@@ -154,21 +158,21 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
                 if (sb + 1 < s_end) load_step(sb + 1);
                 // fragments are double-buffered in registers: the ds_read_b128s of chunk c+1 are issued
                 // before the MFMAs of chunk c, so LDS latency hides behind the matrix pipe.
-                f32x4 af[2][TM], bf[2][TN];
+                bf16x8 af[2][TM], bf[2][TN];
                 auto load_frags = [&](int cc, int fb) {
                     const int u = cc >> 2, c = cc & 3;
-                    const float* Ab = As + (buf * KS + u) * BM * 32;
-                    const float* Bb = Bs + (buf * KS + u) * BN * 32;
-                    const int ls = 2 * c + fh;
+                    const char* Ab = As + (buf * KS + u) * BM * 128;
+                    const char* Bb = Bs + (buf * KS + u) * BN * 128;
+                    const int ls = 2 * c + fh;          // slot = 16 k of MFMA step c, half fh (k = 8*fh + j)
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const int row = (wm * TM + i) * 32 + fr;
-                        af[fb][i] = *reinterpret_cast<const f32x4*>(Ab + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
+                        af[fb][i] = *reinterpret_cast<const bf16x8*>(Ab + row * 128 + ((ls ^ ((row >> 1) & 7)) << 4));
                     }
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const int row = (wn * TN + j) * 32 + fr;
-                        bf[fb][j] = *reinterpret_cast<const f32x4*>(Bb + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
+                        bf[fb][j] = *reinterpret_cast<const bf16x8*>(Bb + row * 128 + ((ls ^ ((row >> 1) & 7)) << 4));
                     }
                 };
                 load_frags(0, 0);
@@ -176,12 +180,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
                 for (int cc = 0; cc < 4 * KS; ++cc) {
                     if (cc + 1 < 4 * KS) load_frags(cc + 1, (cc + 1) & 1);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cc & 1][i][k], bf[cc & 1][j][k], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cc & 1][i], bf[cc & 1][j], acc[i][j], 0, 0, 0);
                 }
                 if (sb + 1 < s_end) store_step(buf ^ 1);
                 __syncthreads();
@@ -261,117 +263,31 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     }
 }
 
-// Split-K second pass: fixed-order sum of the partial slabs (bitwise reproducible) + epilogue.
-__global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvParams p) {
-    int M = p.M;
-    if (p.m_count) {
-        int lim = (*p.m_count) * p.m_per_item;
-        M = lim < M ? lim : M;
-    }
-    const size_t total = (size_t)M * p.Cout;
-    const int ohw = p.OH * p.OW;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int m = (int)(e / p.Cout);
-        const int n = (int)(e - (size_t)m * p.Cout);
-        float val = 0.f;
-        for (int z = 0; z < p.splitk; ++z) val += p.ws[((size_t)z * p.M + m) * p.Cout + n];
-        int co = n, g = 0;
-        if (p.out_mode == 1) { g = n / p.cdec; co = n - g * p.cdec; }
-        if (p.bias) val += p.bias[co];
-        if (p.out_mode == 0) {
-            if (p.res_mode == 1) {
-                val += p.res[(size_t)m * p.Cout + n];
-            } else if (p.res_mode == 2) {
-                const int b = m / ohw;
-                const int rem = m - b * ohw;
-                const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                const int hw2 = (p.OH >> 1) * (p.OW >> 1);
-                val += p.res[((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n];
-            }
-            if (p.relu) val = val > 0.f ? val : 0.f;
-            p.y[(size_t)m * p.y_ld + p.y_coff + n] = val;
-        } else {
-            const int b = m / ohw;
-            const int rem = m - b * ohw;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            const int dy = g >> 1, dx = g & 1;
-            if (p.relu) val = val > 0.f ? val : 0.f;
-            p.y[(((size_t)b * 2 * p.OH + 2 * oy + dy) * (2 * p.OW) + 2 * ox + dx) * p.cdec + co] = val;
-        }
-    }
-}
 
 template <int WM, int WN, int TM, int TN, int KS>
-static int launch_cfg(const ConvParams& p, hipStream_t s) {
+static int launch_bf16(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
-    const size_t lds_stage = (size_t)2 * KS * (BM + BN) * 32 * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+    const size_t lds_stage = (size_t)2 * KS * (BM + BN) * 128, lds_c = (size_t)BM * (BN + 4) * sizeof(float);
     const size_t lds = lds_stage > lds_c ? lds_stage : lds_c;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, KS>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16<WM, WN, TM, TN, KS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     const int grid_x = (p.m_count && tiles > 1024) ? 1024 : tiles;
-    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, KS>), dim3(grid_x, p.splitk), dim3(256), lds, s, p);
-    if (p.splitk > 1) {
-        const size_t total = (size_t)p.M * p.Cout;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(conv_splitk_reduce, dim3(blocks), dim3(256), 0, s, p);
-    }
+    hipLaunchKernelGGL((conv_igemm_bf16<WM, WN, TM, TN, KS>), dim3(grid_x, p.splitk), dim3(256), lds, s, p);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 
-int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s) {
-    if (p.M <= 0 || p.Cout <= 0 || p.steps_total <= 0) return APSE_E_INVALID;
-    if (p.res_mode != 0 && (p.Cout & 3) != 0) return APSE_E_INVALID;      // residual rows are read as float4
-    if (p.prec == 1) {
-        int rc = apse_launch_conv_bf16(p, cfg, s);
-        if (rc == APSE_OK && p.splitk > 1) {
-            const size_t total = (size_t)p.M * p.Cout;
-            int blocks = (int)((total + 255) / 256);
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(conv_splitk_reduce, dim3(blocks), dim3(256), 0, s, p);
-        }
-        return rc;
-    }
+// The caller (apse_launch_conv) adds the split-K reduce pass.
+int apse_launch_conv_bf16(const ConvParams& p, int cfg, hipStream_t s) {
     switch (cfg) {
-        case 0: return launch_cfg<2, 2, 2, 2, 1>(p, s);
-        case 1: return launch_cfg<2, 2, 1, 1, 2>(p, s);
-        case 2: return launch_cfg<4, 1, 1, 1, 2>(p, s);
-        case 3: return launch_cfg<4, 1, 1, 2, 1>(p, s);
+        case 0: return launch_bf16<2, 2, 2, 2, 1>(p, s);
+        case 1: return launch_bf16<2, 2, 1, 1, 2>(p, s);
+        case 2: return launch_bf16<4, 1, 1, 1, 2>(p, s);
+        case 3: return launch_bf16<4, 1, 1, 2, 1>(p, s);
         default: return APSE_E_INVALID;
     }
-}
-
-// Tile/split heuristic (tools/conv_sweep.py on MI355X): fill >= ~2 resident blocks per CU; prefer the
-// largest tile that does; for small-M layers trade tile size against split-K:
-//   large K   -> 128x128 tiles with the K range split across blocks (fc1, res4/res5 3x3),
-//   medium K  -> 64x64 tiles (unsplit once there are >= 192 of them),
-//   tiny K, wide N (res4 conv3) -> 128x64 tiles.
-int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk) {
-    *splitk = 1;
-    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
-    auto split_for = [&](int t, int min_steps_per_split) {
-        int sk = (512 + t / 2) / t;
-        if (sk > steps / min_steps_per_split) sk = steps / min_steps_per_split;
-        if (sk > 64) sk = 64;
-        return sk < 1 ? 1 : sk;
-    };
-    if (Cout <= 32) return 2;
-    if (Cout <= 64) return tiles(128, 64) >= 192 ? 3 : 1;
-    const int t128 = tiles(128, 128);
-    if (t128 >= 224) {
-        if (t128 < 384 && steps <= 16 && tiles(128, 64) >= 384) return 3;
-        return 0;
-    }
-    if (t128 >= 32 && steps >= 64) {
-        *splitk = split_for(t128, 8);
-        return 0;
-    }
-    const int t64 = tiles(64, 64);
-    if (t64 < 192 && steps >= 16) *splitk = split_for(t64, 4);
-    return 1;
 }

@@ -262,6 +262,8 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     p.steps_total = KH * (KWCp / 32);
     p.splitk = 1;
     p.out_mode = sp.deconv ? 1 : 0;
+    // bf16 matrix cores for the bulk GEMMs; decision layers (narrow heads) and the association FC stay exact f32
+    p.prec = (c->cfg.compute_dtype == 1 && Cout > 32 && sp.name != "assoc_fc") ? 1 : 0;
     p.cdec = sp.deconv ? Cout / 4 : 0;
     const int out_c = sp.deconv ? Cout / 4 : (y_ld_override > 0 ? y_ld_override : Cout);
     const int oh = sp.deconv ? 2 * p.OH : p.OH, ow = sp.deconv ? 2 * p.OW : p.OW;
@@ -583,7 +585,7 @@ static int build_plan(apse_ctx* c) {
 // ================================================================================================ C ABI
 extern "C" {
 
-const char* apse_version(void) { return "apse_hip 0.1 (gfx950, f32 MFMA)"; }
+const char* apse_version(void) { return "apse_hip 0.2 (gfx950, f32 / bf16 MFMA)"; }
 
 int apse_create(const apse_config* cfg, apse_ctx** out) {
     if (!cfg || !out) return fail(nullptr, APSE_E_INVALID, "null argument");
@@ -969,6 +971,7 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
     p.Cout = d->Cout; p.relu = d->relu; p.res_mode = d->res_mode;
     p.M = p.B * p.OH * p.OW; p.m_per_item = p.OH * p.OW;
     p.y_ld = d->Cout; p.steps_total = p.KH * (p.KWCp / 32);
+    p.prec = d->prec ? 1 : 0;
     int sk = 1;
     int cfg = apse_conv_pick_cfg(p.M, p.Cout, p.steps_total, &sk);
     if (d->cfg >= 0) { cfg = d->cfg; sk = 1; }

@@ -25,8 +25,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CFG_NAMES = ["conv_igemm_f32<128x128>", "conv_igemm_f32<64x64>", "conv_igemm_f32<128x32>", "conv_igemm_f32<128x64>"]
+CFG_NAMES = ["conv_igemm<128x128>", "conv_igemm<64x64>", "conv_igemm<128x32>", "conv_igemm<128x64>"]
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 dense
 
 
 def main():
@@ -44,6 +45,9 @@ def main():
                     help="HIP-event pairs around every convolution launch on every n-th timed step (each pair costs "
                          "~5 us of stream time, ~1.5 ms per fully instrumented frame)")
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"],
+                    help="f32 = exact-f32 MFMA (reference numerics, BASELINE configs[1]); bf16 = bf16 matrix cores with "
+                         "f32 accumulate/storage for the bulk GEMMs (configs[2]/[4] style)")
     ap.add_argument("--bg-bias", type=float, default=None)
     args = ap.parse_args()
 
@@ -78,6 +82,7 @@ def main():
     asd = synthetic_association_state(1)
     cfg = setup_cfg(device="cuda:%d" % local_rank)
     cfg.APSE.MAX_BATCH = B
+    cfg.APSE.DTYPE = args.dtype
     tracker = RcnnTracker(cfg, (H, W), asd, detector_state=sd)
     model = tracker.predictor.model
 
@@ -153,20 +158,21 @@ def main():
         dom = int(np.argmax(prof[:, 0]))
         ms, fl, nl = prof[dom]
         achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         total_conv_ms = float(prof[:, 0].sum())
         flops_frame = model.flops(1, P_sum / max(args.steps * B, 1), N_sum / max(args.steps * B, 1))
         out = {
             "metric": "4K UAV frames/sec (whole node)", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "p50_ms_per_frame": round(1000.0 * float(np.median(lat)) / B, 3),
-            "config": {"workload": "static synthetic 3840x2160 sequence, batch=%d f32, Mask R-CNN R-%s-FPN, %d GPU(s), "
-                                   "frames sharded per rank" % (B, "101" if blocks == (3, 4, 23, 3) else str(blocks), world),
+            "config": {"workload": "static synthetic 3840x2160 sequence, batch=%d %s, Mask R-CNN R-%s-FPN, %d GPU(s), "
+                                   "frames sharded per rank" % (B, args.dtype, "101" if blocks == (3, 4, 23, 3) else str(blocks), world),
                        "frame": "%dx%d" % (W, H), "batch_per_gpu": B, "proposals_per_frame": P_sum / max(args.steps * B, 1),
                        "detections_per_frame": N_sum / max(args.steps * B, 1),
                        "gflop_per_frame_algorithmic": round(flops_frame / 1e9, 2)},
             "roofline": {"bound": "mfma", "kernel": CFG_NAMES[dom], "achieved": round(achieved, 3),
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": None, "avg_launch_ms": round(ms / max(nl, 1), 5), "launches": int(nl),
                          "all_kernels": {CFG_NAMES[k]: {"ms": round(float(prof[k, 0]), 3),
                                                         "tflops": round(float(prof[k, 1] / max(prof[k, 0], 1e-9) / 1e9), 3),

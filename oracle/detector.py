@@ -30,7 +30,18 @@ DEFAULT_CFG = dict(
     num_classes=4, score_thresh=0.5, box_nms=0.5, dets_per_image=100,
     box_pool=7, mask_pool=14, mask_thresh=0.5,
     bbox_weights=(10.0, 10.0, 5.0, 5.0),
+    # bf16=True emulates the product's "bf16 matrix cores, f32 storage" mode: FrozenBN folded into the
+    # filters in f32, filters and layer inputs rounded to bf16 (nearest-even), f32 accumulation and f32
+    # outputs; the narrow decision heads (RPN logits/deltas, box predictor, mask logits) stay f32.
+    bf16=False,
 )
+
+F32_LAYERS = ("proposal_generator.rpn_head.objectness_logits", "proposal_generator.rpn_head.anchor_deltas",
+              "roi_heads.mask_head.predictor")
+
+
+def _r16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
 
 
 def resize_shape(h, w, min_size=800, max_size=1333):
@@ -59,6 +70,14 @@ class DetectorOracle:
     def _conv(self, x, name, stride=1, padding=0, relu=False):
         w = self.sd[name + ".weight"]
         b = self.sd.get(name + ".bias")
+        if self.cfg["bf16"] and name not in F32_LAYERS:
+            if (name + ".norm.weight") in self.sd:
+                g = self.sd[name + ".norm.weight"]
+                scale = g * (1.0 / torch.sqrt(self.sd[name + ".norm.running_var"] + 1e-5))
+                b = self.sd[name + ".norm.bias"] - self.sd[name + ".norm.running_mean"] * scale
+                w = w * scale.view(-1, 1, 1, 1)
+            y = F.conv2d(_r16(x), _r16(w), b, stride=stride, padding=padding)
+            return F.relu(y) if relu else y
         y = F.conv2d(x, w, b, stride=stride, padding=padding)
         if (name + ".norm.weight") in self.sd:
             # FrozenBatchNorm2d: x * scale + bias with scale = w * rsqrt(var + eps)
@@ -173,8 +192,9 @@ class DetectorOracle:
     def box_features(self, feats, proposals):
         pooled = ops.roi_pooler([feats[k][0] for k in ("p2", "p3", "p4", "p5")], proposals, self.cfg["box_pool"])
         x = pooled.flatten(1)
-        x = F.relu(F.linear(x, self.sd["roi_heads.box_head.fc1.weight"], self.sd["roi_heads.box_head.fc1.bias"]))
-        x = F.relu(F.linear(x, self.sd["roi_heads.box_head.fc2.weight"], self.sd["roi_heads.box_head.fc2.bias"]))
+        q = _r16 if self.cfg["bf16"] else (lambda t: t)
+        x = F.relu(F.linear(q(x), q(self.sd["roi_heads.box_head.fc1.weight"]), self.sd["roi_heads.box_head.fc1.bias"]))
+        x = F.relu(F.linear(q(x), q(self.sd["roi_heads.box_head.fc2.weight"]), self.sd["roi_heads.box_head.fc2.bias"]))
         cls = F.linear(x, self.sd["roi_heads.box_predictor.cls_score.weight"], self.sd["roi_heads.box_predictor.cls_score.bias"])
         reg = F.linear(x, self.sd["roi_heads.box_predictor.bbox_pred.weight"], self.sd["roi_heads.box_predictor.bbox_pred.bias"])
         return dict(pooled=pooled, cls_logits=cls, deltas=reg)
@@ -212,7 +232,8 @@ class DetectorOracle:
         pooled = x
         for i in range(1, 5):
             x = self._conv(x, "roi_heads.mask_head.mask_fcn%d" % i, padding=1, relu=True)
-        x = F.relu(F.conv_transpose2d(x, self.sd["roi_heads.mask_head.deconv.weight"],
+        q = _r16 if self.cfg["bf16"] else (lambda t: t)
+        x = F.relu(F.conv_transpose2d(q(x), q(self.sd["roi_heads.mask_head.deconv.weight"]),
                                       self.sd["roi_heads.mask_head.deconv.bias"], stride=2))
         logits = self._conv(x, "roi_heads.mask_head.predictor")
         probs = logits.sigmoid()[torch.arange(n), classes]

@@ -65,6 +65,35 @@ def test_conv2d_parity(case, logdir):
     assert st["rel_to_max"] < 2e-5, st          # f32 tolerance: accumulation-order noise only
 
 
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_bf16_parity(case, logdir):
+    """bf16 matrix-core variant: operands rounded to bf16 at staging, f32 accumulate/storage.  Reference =
+    torch CPU f32 convolution of the bf16-rounded operands (same quantisation points)."""
+    from hip_helpers import hip_conv2d, err_stats
+    import zlib
+    name, B, Cin, H, W, Cout, K, stride, pad, relu, res_mode, cfg, splitk = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    r16 = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    ref = F.conv2d(r16(x), r16(w), b, stride=stride, padding=pad)
+    res = None
+    if res_mode == 1:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res
+    elif res_mode == 2:
+        res = torch.randn(B, Cout, ref.shape[2] // 2, ref.shape[3] // 2, generator=g)
+        ref = ref + F.interpolate(res, scale_factor=2, mode="nearest")
+    if relu:
+        ref = F.relu(ref)
+    out = hip_conv2d(x, w, b, stride, pad, relu, res, res_mode, cfg, splitk, prec=1)
+    st = err_stats(out, ref)
+    _log(logdir, "conv_bf16/" + name, st)
+    assert st["nan"] == 0
+    assert st["rel_to_max"] < 2e-5, st          # products of bf16 values are exact in f32: order-of-sum noise only
+
+
 def test_maxpool(logdir):
     from apse_uav_amd import _lib
     from hip_helpers import to_nhwc
