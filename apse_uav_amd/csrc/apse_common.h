@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 struct ConvParams {
     const float* x;
     const float* w;
+    const uint16_t* w16;  // same layout as w, pre-rounded to bf16 (bf16 kernel only; nullptr -> round w on the fly)
     const float* bias;    // [Cout_p] or nullptr
     const float* res;     // residual (res_mode != 0)
     float* y;

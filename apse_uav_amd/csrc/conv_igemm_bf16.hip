@@ -115,11 +115,19 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
 #pragma unroll
                 for (int i = 0; i < BP; ++i) {
                     const int n = n0 + srow + 32 * i;
-                    const float* wp = p.w + (size_t)n * w_row + (size_t)r * p.KWCp + q;
-                    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-                    if (qa) lo = *reinterpret_cast<const f32x4*>(wp);
-                    if (qb) hi = *reinterpret_cast<const f32x4*>(wp + 4);
-                    rb[u][i] = cvt8(lo, hi);
+                    const size_t wo = (size_t)n * w_row + (size_t)r * p.KWCp + q;
+                    if (p.w16) {                     // filters pre-rounded to bf16: one 16-byte load per slot
+                        bf16x8 v;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+                        if (qa) v = *reinterpret_cast<const bf16x8*>(p.w16 + wo);
+                        rb[u][i] = v;
+                    } else {
+                        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+                        if (qa) lo = *reinterpret_cast<const f32x4*>(p.w + wo);
+                        if (qb) hi = *reinterpret_cast<const f32x4*>(p.w + wo + 4);
+                        rb[u][i] = cvt8(lo, hi);
+                    }
                 }
             }
         };

@@ -241,9 +241,24 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     pack_oihw(rows.data(), Cout, Cin, KH, KW, cin_p, nullptr, packed.data(), KWCp);
     std::vector<float> bias_p(Cout_p, 0.f);
     for (size_t i = 0; i < bias.size(); ++i) bias_p[i] = bias[i];
-    float* wd = dupload(c, packed);
+    const bool use_bf16 = (c->cfg.compute_dtype == 1 && Cout > 32 && sp.name != "assoc_fc");
+    float* wd = nullptr;
+    uint16_t* wd16 = nullptr;
+    if (use_bf16) {
+        // filters pre-rounded to bf16 (round-to-nearest-even, the rounding v_cvt_pk_bf16_f32 applies)
+        std::vector<uint16_t> p16(packed.size());
+        for (size_t i = 0; i < packed.size(); ++i) {
+            uint32_t b;
+            memcpy(&b, &packed[i], 4);
+            if ((b & 0x7fffffffu) > 0x7f800000u) p16[i] = (uint16_t)((b >> 16) | 0x40);       // NaN stays NaN
+            else p16[i] = (uint16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+        }
+        wd16 = dupload(c, p16);
+    } else {
+        wd = dupload(c, packed);
+    }
     float* bd = dupload(c, bias_p);
-    if (!wd || !bd) return fail(c, APSE_E_NOMEM, "weight upload failed at " + sp.name);
+    if ((!wd && !wd16) || !bd) return fail(c, APSE_E_NOMEM, "weight upload failed at " + sp.name);
 
     Step st;
     st.kind = S_CONV;
@@ -253,7 +268,7 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     cs.b_mult = in_items_mult;
     cs.count_kind = count_kind;
     ConvParams& p = cs.p;
-    p.x = in.p; p.w = wd; p.bias = bd; p.res = res; p.res_mode = res_mode;
+    p.x = in.p; p.w = wd; p.w16 = wd16; p.bias = bd; p.res = res; p.res_mode = res_mode;
     p.H = in.H; p.W = in.W; p.cin_log2 = apse_ilog2(cin_p);
     p.KH = KH; p.KW = KW; p.stride = sp.stride; p.pad = sp.pad; p.KWCp = KWCp;
     p.OH = (in.H + 2 * sp.pad - KH) / sp.stride + 1;
@@ -263,7 +278,7 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     p.splitk = 1;
     p.out_mode = sp.deconv ? 1 : 0;
     // bf16 matrix cores for the bulk GEMMs; decision layers (narrow heads) and the association FC stay exact f32
-    p.prec = (c->cfg.compute_dtype == 1 && Cout > 32 && sp.name != "assoc_fc") ? 1 : 0;
+    p.prec = use_bf16 ? 1 : 0;
     p.cdec = sp.deconv ? Cout / 4 : 0;
     const int out_c = sp.deconv ? Cout / 4 : (y_ld_override > 0 ? y_ld_override : Cout);
     const int oh = sp.deconv ? 2 * p.OH : p.OH, ow = sp.deconv ? 2 * p.OW : p.OW;
