@@ -29,14 +29,14 @@ int apse_k_chw_norm(const float*, float*, int, int, int, int, int, const float*,
 int apse_k_maxpool3x3s2(const float*, float*, int, int, int, int, hipStream_t);
 int apse_k_subsample2(const float*, float*, int, int, int, int, hipStream_t);
 int apse_k_nhwc_to_nchw(const float*, float*, int, int, int, hipStream_t);
-int apse_k_rpn_topk_stage(const RpnLevels*, const TopkJob*, int, uint64_t*, int, int, hipStream_t);
+int apse_k_rpn_topk_stage(const RpnLevels*, const TopkJob*, int, uint64_t*, int, int, uint32_t*, hipStream_t);
 int apse_k_rpn_decode(const RpnLevels*, int, const uint64_t*, int, const int*, float, float, float, float*, float*, int*,
                       uint32_t*, int, hipStream_t);
 int apse_k_nms_percat(const float*, const float*, const int*, int, int, int, const uint32_t*, float, int*, int*, int,
                       void*, int, hipStream_t);
 size_t apse_nms_scratch_bytes(int slots);
-int apse_k_rank_final(const float*, const float*, int, const int*, const int*, int, int, float*, float*, int*, int*, int,
-                      hipStream_t);
+int apse_k_rank_final(const float*, const float*, int, const int*, const int*, int, int, float*, float*, int*, int*, uint32_t*,
+                      int, hipStream_t);
 int apse_k_box_candidates(const float*, int, int, const float*, const int*, int, float, float, float, const float*, float,
                           float*, float*, int*, uint32_t*, float*, int, hipStream_t);
 int apse_k_pack_detections(const float*, const float*, const int*, const int*, int, int, int, float*, float*, int*, int*,
@@ -47,7 +47,7 @@ int apse_k_l2_normalize(const float*, float*, int, const int*, int, hipStream_t)
 int apse_k_sqdist(const float*, const float*, int, int, int, float*, hipStream_t);
 int apse_k_mask_paste(const PasteParams*, int, int*, int*, hipStream_t);
 int apse_k_closest_points(const uint64_t*, const int*, const int*, const int*, const int*, const int*, const int*, int, int,
-                          int, int, int, int*, hipStream_t);
+                          int, int, int, int*, unsigned long long*, hipStream_t);
 int apse_k_closest_single(const uint64_t*, int, int, int, float, float, unsigned long long*, hipStream_t);
 struct UndistortParams { double ir[9]; double k[12]; double fx, fy, u0, v0; int H, W; int do_undistort, do_gamma; };
 int apse_k_undistort_gamma(const UndistortParams*, const uint8_t*, uint8_t*, const uint8_t*, int, hipStream_t);
@@ -98,8 +98,9 @@ struct apse_ctx {
     // results block (device) and layout
     apse_results_layout lay; uint8_t* res = nullptr;
     // mask tail
-    uint64_t* bits = nullptr; unsigned long long* sums = nullptr; int wpr = 0;
+    uint64_t* bits = nullptr; unsigned long long* sums = nullptr; unsigned long long* cp_keys = nullptr; int wpr = 0;
     float* emb_raw = nullptr;
+    bool box_maxc_clean = false;
     int hint_total = 8;      // detections seen in the previous forward: sizes the tiles of the packed-list GEMMs
     // per-kernel profiling with HIP events on the caller's stream (bench.py roofline)
     bool prof_on = false; std::vector<hipEvent_t> ev_pool; int ev_used = 0;
@@ -576,6 +577,7 @@ static int build_plan(apse_ctx* c) {
     c->wpr = (g.frame_w + 63) / 64;
     c->bits = dalloc<uint64_t>(c, (size_t)NM * g.frame_h * c->wpr, false);
     c->sums = dalloc<unsigned long long>(c, (size_t)NM * 3);
+    c->cp_keys = dalloc<unsigned long long>(c, (size_t)NM * KD);
     if (!c->bits) return fail(c, APSE_E_NOMEM, "mask bit planes alloc");
     // ---- association head: roi_pool(p2) -> FC (RxR valid conv) -> L2 normalise
     const int R = g.assoc_roi;
@@ -607,7 +609,7 @@ int apse_create(const apse_config* cfg, apse_ctx** out) {
     if (cfg->struct_size != (int)sizeof(apse_config)) return fail(nullptr, APSE_E_INVALID, "apse_config size mismatch");
     if (cfg->max_batch < 1 || cfg->max_batch > 64 || cfg->rpn_pre_topk > 1000 || cfg->rpn_post_topk > 1000 ||
         cfg->dets_per_image > 100 || cfg->num_classes < 1 || cfg->num_classes > 6 || cfg->embed_dim > 256 ||
-        (cfg->frame_w & 3) != 0)
+        (cfg->frame_w & 3) != 0 || cfg->max_batch * cfg->dets_per_image > 1024)
         return fail(nullptr, APSE_E_INVALID, "config out of supported range");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -697,10 +699,10 @@ int apse_rpn(apse_ctx* c, int batch, void* stream) {
     int rc = run_plan(c, c->rpnhead, batch, s);
     if (rc) return rc;
     for (size_t i = 0; i < c->stages.size(); ++i) {
-        rc = apse_k_rpn_topk_stage(c->rl_dev, c->stage_dev[i], (int)c->stages[i].size(), c->lists, c->nslots, batch, s);
+        rc = apse_k_rpn_topk_stage(c->rl_dev, c->stage_dev[i], (int)c->stages[i].size(), c->lists, c->nslots, batch,
+                                   i == 0 ? c->maxc : nullptr, s);
         if (rc) return fail(c, rc, "rpn top-k stage launch failed");
     }
-    hipMemsetAsync(c->maxc, 0, sizeof(uint32_t) * g.max_batch, s);
     rc = apse_k_rpn_decode(c->rl_dev, g.rpn_pre_topk, c->lists, c->nslots, c->final_slot_dev, (float)g.image_h, (float)g.image_w,
                            (float)log(1000.0 / 16.0), c->dec_boxes, c->dec_scores, c->dec_valid, c->maxc, batch, s);
     if (rc) return fail(c, rc, "rpn decode launch failed");
@@ -709,7 +711,8 @@ int apse_rpn(apse_ctx* c, int batch, void* stream) {
     if (rc) return fail(c, rc, "rpn nms launch failed");
     int* propcnt = reinterpret_cast<int*>(c->res + c->lay.prop_count);
     rc = apse_k_rank_final(c->dec_boxes, c->dec_scores, 5 * g.rpn_pre_topk, c->keep_idx, c->keep_cnt, 5, g.rpn_post_topk, c->props,
-                           c->prop_scores, c->prop_entry, propcnt, batch, s);
+                           c->prop_scores, c->prop_entry, propcnt, c->maxc + g.max_batch, batch, s);
+    c->box_maxc_clean = true;
     if (rc) return fail(c, rc, "rpn rank launch failed");
     return APSE_OK;
 }
@@ -734,7 +737,8 @@ int apse_box_head(apse_ctx* c, int batch, void* stream) {
     rc = run_plan(c, c->boxhead, batch, s);
     if (rc) return rc;
     const float wts[4] = {10.f, 10.f, 5.f, 5.f};
-    hipMemsetAsync(c->maxc + g.max_batch, 0, sizeof(uint32_t) * g.max_batch, s);
+    if (!c->box_maxc_clean) hipMemsetAsync(c->maxc + g.max_batch, 0, sizeof(uint32_t) * g.max_batch, s);
+    c->box_maxc_clean = false;
     rc = apse_k_box_candidates(c->t["box_pred"].p, 32, K, c->props, propcnt, P, (float)g.image_h, (float)g.image_w, g.score_thresh,
                                wts, (float)log(1000.0 / 16.0), c->cand_boxes, c->cand_scores, c->cand_valid,
                                c->maxc + g.max_batch, c->probs, batch, s);
@@ -743,7 +747,7 @@ int apse_box_head(apse_ctx* c, int batch, void* stream) {
                            c->keep_cnt, K, c->nms_scratch, batch, s);
     if (rc) return fail(c, rc, "box nms launch failed");
     rc = apse_k_rank_final(c->cand_boxes, c->cand_scores, P * K, c->keep_idx, c->keep_cnt, K, g.dets_per_image, c->det_boxes,
-                           c->det_scores, c->det_entry, c->det_cnt, batch, s);
+                           c->det_scores, c->det_entry, c->det_cnt, nullptr, batch, s);
     if (rc) return fail(c, rc, "box rank launch failed");
     rc = pack_from_dets(c, batch, s);
     return rc ? fail(c, rc, "pack launch failed") : APSE_OK;
@@ -800,7 +804,7 @@ int apse_mask_tail(apse_ctx* c, int batch, void* stream) {
     if (rc) return fail(c, rc, "mask paste launch failed");
     rc = apse_k_closest_points(c->bits, p.rect, p.valid, (int*)(r + c->lay.centroid), (int*)(r + c->lay.img),
                                (int*)(r + c->lay.offset), total, NM, g.dets_per_image, g.frame_h, g.frame_w, c->wpr,
-                               (int*)(r + c->lay.closest), s);
+                               (int*)(r + c->lay.closest), c->cp_keys, s);
     return rc ? fail(c, rc, "closest points launch failed") : APSE_OK;
 }
 
@@ -1056,7 +1060,7 @@ int apse_nms_rank(const float* boxes, const float* scores, const int* valid, int
     void* scratch = nullptr;
     if (hipMalloc(&scratch, apse_nms_scratch_bytes(8)) != hipSuccess) return APSE_E_NOMEM;
     int rc = apse_k_nms_percat(boxes, scores, valid, n, cat_div, cat_mod, maxc, thr, keep_idx, keep_cnt, ncat, scratch, 1, s);
-    if (!rc) rc = apse_k_rank_final(boxes, scores, n, keep_idx, keep_cnt, ncat, topk, out_boxes, out_scores, out_index, out_count, 1, s);
+    if (!rc) rc = apse_k_rank_final(boxes, scores, n, keep_idx, keep_cnt, ncat, topk, out_boxes, out_scores, out_index, out_count, nullptr, 1, s);
     hipStreamSynchronize(s);
     hipFree(keep_idx); hipFree(keep_cnt); hipFree(maxc); hipFree(scratch);
     return rc;

@@ -41,6 +41,7 @@ __global__ void det_postprocess(const PasteParams p, int n_max) {
     p.boxes_out[i * 4 + 0] = x0; p.boxes_out[i * 4 + 1] = y0; p.boxes_out[i * 4 + 2] = x1; p.boxes_out[i * 4 + 3] = y1;
     const int ok = ((x1 - x0) > 0.f) && ((y1 - y0) > 0.f);
     p.valid[i] = ok;
+    p.sums[i * 3 + 0] = 0; p.sums[i * 3 + 1] = 0; p.sums[i * 3 + 2] = 0;       // paste_masks accumulates into these
     int rx0 = (int)fmaxf(floorf(x0) - 1.f, 0.f), ry0 = (int)fmaxf(floorf(y0) - 1.f, 0.f);
     int rx1 = (int)fminf(ceilf(x1) + 1.f, w), ry1 = (int)fminf(ceilf(y1) + 1.f, h);
     if (!ok) { rx1 = rx0; ry1 = ry0; }
@@ -48,23 +49,42 @@ __global__ void det_postprocess(const PasteParams p, int n_max) {
 }
 
 #define PASTE_ROWSPLIT 16
-// 1-D grid of PASTE_BLOCKS blocks striding over (detection, row-split) items of the LIVE detections
-// only; 256 threads = 4 waves; wave w of split c handles window rows y0 + (c*4 + w) + k*4*PASTE_ROWSPLIT.
-// A wave covers 64 pixels per step; ballot -> one 64-bit word of the bit plane.
-#define PASTE_BLOCKS 512
+// Work item = (detection, band of PASTE_BAND window rows); a 1-D grid strides over the items of the LIVE
+// detections only, so one frame-sized window is spread over ~135 blocks instead of 16.  256 threads = 4
+// waves; a wave covers 64 pixels per step; ballot -> one 64-bit word of the bit plane.
+#define MT_MAXDET 1024            // packed detections per forward (apse_create enforces max_batch * dets_per_image <= this)
+#define PASTE_BLOCKS 1024
+#define PASTE_BAND 16
 __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_max) {
     __shared__ float prob[32 * 32];
     __shared__ unsigned long long red[4][3];
+    __shared__ int band0[MT_MAXDET + 1];       // first item of each detection (prefix over live detections)
     const int total = *p.total < n_max ? *p.total : n_max;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int item = blockIdx.x; item < total * PASTE_ROWSPLIT; item += gridDim.x) {
-        const int i = item / PASTE_ROWSPLIT, split = item - i * PASTE_ROWSPLIT;
-        if (!p.valid[i]) continue;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < total && i < MT_MAXDET; ++i) {
+            band0[i] = acc;
+            const int rows = p.valid[i] ? p.rect[i * 4 + 3] - p.rect[i * 4 + 1] : 0;
+            acc += (rows + PASTE_BAND - 1) / PASTE_BAND;
+        }
+        band0[total < MT_MAXDET ? total : MT_MAXDET] = acc;
+    }
+    __syncthreads();
+    const int nd = total < MT_MAXDET ? total : MT_MAXDET;
+    const int nitems = band0[nd];
+    int cur = -1;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        int i = 0;
+        while (i + 1 < nd && band0[i + 1] <= item) ++i;
+        const int band = item - band0[i];
         const int M = p.M;
-        const int c = p.cls[i];
-        const float* lg = p.logits + (size_t)i * M * M * p.ldc + c;
-        __syncthreads();                    // previous item's prob/red readers are done
-        for (int t = threadIdx.x; t < M * M; t += blockDim.x) prob[t] = 1.0f / (1.0f + expf(-lg[(size_t)t * p.ldc]));
+        if (i != cur) {
+            const float* lg = p.logits + (size_t)i * M * M * p.ldc + p.cls[i];
+            __syncthreads();                    // previous item's prob readers are done
+            for (int t = threadIdx.x; t < M * M; t += blockDim.x) prob[t] = 1.0f / (1.0f + expf(-lg[(size_t)t * p.ldc]));
+            cur = i;
+        }
         __syncthreads();
         const int rx0 = p.rect[i * 4 + 0], ry0 = p.rect[i * 4 + 1], rx1 = p.rect[i * 4 + 2], ry1 = p.rect[i * 4 + 3];
         const float bx0 = p.boxes_out[i * 4 + 0], by0 = p.boxes_out[i * 4 + 1];
@@ -74,7 +94,9 @@ __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_ma
         uint64_t* bits = p.bits + (size_t)i * p.out_h * p.words_per_row;
         unsigned long long mass = 0, sx = 0, sy = 0;
         const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
-        for (int y = ry0 + split * 4 + wave; y < ry1; y += 4 * PASTE_ROWSPLIT) {
+        const int yb = ry0 + band * PASTE_BAND;
+        const int ye = (yb + PASTE_BAND) < ry1 ? (yb + PASTE_BAND) : ry1;
+        for (int y = yb + wave; y < ye; y += 4) {
             // normalised y, grid_sample unnormalise (align_corners=False)
             const float gy = ((float)y + 0.5f - by0) / bh * 2.0f - 1.0f;
             const float iy = ((gy + 1.0f) * Mf - 1.0f) / 2.0f;
@@ -107,6 +129,7 @@ __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_ma
         for (int o = 32; o > 0; o >>= 1) {
             mass += __shfl_xor(mass, o); sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o);
         }
+        __syncthreads();                        // red[] of the previous item has been consumed
         if (lane == 0) { red[wave][0] = mass; red[wave][1] = sx; red[wave][2] = sy; }
         __syncthreads();
         if (threadIdx.x < 3) {
@@ -127,58 +150,107 @@ __global__ void mask_centroids(const unsigned long long* __restrict__ sums, cons
     cent[i * 2 + 1] = m ? (int)(sums[i * 3 + 2] / m) : -1;
 }
 
-// 1-D grid striding over the pairs (mask i, jl-th detection of the same image) of the live list;
-// closest[i][jl] = (x, y) 1-based, or (-1,-1).
+// closest[i][jl] for every detection i and every target jl of the same image.  Work item = (mask i,
+// band of CP_BAND window rows); each thread scans its words once per group of 8 targets and keeps 8
+// running minima of (f32 distance bits, row-major index); block minima are merged with atomicMin on
+// 64-bit keys (order-independent), closest_finalize turns keys into 1-based (x, y).
+#define CP_BAND 32
 __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict__ bits_all, const int* __restrict__ rect,
                                                       const int* __restrict__ valid, const int* __restrict__ cent,
                                                       const int* __restrict__ img, const int* __restrict__ offset,
-                                                      const int* __restrict__ total, int kd, int out_h, int out_w,
-                                                      int words_per_row, int* __restrict__ closest) {
-    __shared__ unsigned long long best[4];
-    const int n = *total;
-    for (int pair = blockIdx.x; pair < n * kd; pair += gridDim.x) {
-        const int i = pair / kd, jl = pair - i * kd;
-        const int j = offset[img[i]] + jl;
-        if (j >= offset[img[i] + 1]) continue;
-        int* o = closest + ((size_t)i * kd + jl) * 2;
-        if (!valid[i] || cent[j * 2] < 0) {
-            if (threadIdx.x == 0) { o[0] = -1; o[1] = -1; }
-            continue;
+                                                      const int* __restrict__ total, int n_max, int kd, int out_h, int out_w,
+                                                      int words_per_row, unsigned long long* __restrict__ keys) {
+    __shared__ int band0[MT_MAXDET + 1];
+    __shared__ unsigned long long best[4][8];
+    const int n = *total < n_max ? *total : n_max;
+    const int nd = n < MT_MAXDET ? n : MT_MAXDET;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < nd; ++i) {
+            band0[i] = acc;
+            const int rows = valid[i] ? rect[i * 4 + 3] - rect[i * 4 + 1] : 0;
+            acc += (rows + CP_BAND - 1) / CP_BAND;
         }
-        const float px = (float)cent[j * 2], py = (float)cent[j * 2 + 1];
+        band0[nd] = acc;
+    }
+    __syncthreads();
+    const int nitems = band0[nd];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        int i = 0;
+        while (i + 1 < nd && band0[i + 1] <= item) ++i;
+        const int band = item - band0[i];
+        const int j0 = offset[img[i]], j1 = offset[img[i] + 1];
         const int rx0 = rect[i * 4 + 0], ry0 = rect[i * 4 + 1], rx1 = rect[i * 4 + 2], ry1 = rect[i * 4 + 3];
         const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
-        const int nw = w1 - w0, nrows = ry1 - ry0;
+        const int nw = w1 - w0;
+        const int yb = ry0 + band * CP_BAND;
+        const int nrows = ((yb + CP_BAND) < ry1 ? (yb + CP_BAND) : ry1) - yb;
         const uint64_t* bits = bits_all + (size_t)i * out_h * words_per_row;
-        unsigned long long b = ~0ull;
-        for (int t = threadIdx.x; t < nw * nrows; t += blockDim.x) {
-            const int ry = t / nw, w = w0 + (t - ry * nw);
-            const int y = ry0 + ry;
-            uint64_t word = bits[(size_t)y * words_per_row + w];
-            const float dy = (float)(y + 1) - py;
-            const float dy2 = dy * dy;
-            while (word) {
-                const int bit = __ffsll((long long)word) - 1;
-                word &= word - 1;
-                const int x = (w << 6) + bit;
-                const float dx = (float)(x + 1) - px;
-                const float d = dx * dx + dy2;
-                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(y * out_w + x);
-                b = key < b ? key : b;
+        for (int jg = j0; jg < j1; jg += 8) {
+            float px[8], py[8];
+            unsigned long long b[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = jg + k;
+                const bool ok = j < j1 && cent[j * 2] >= 0;
+                px[k] = ok ? (float)cent[j * 2] : 0.f;
+                py[k] = ok ? (float)cent[j * 2 + 1] : 0.f;
+                b[k] = ~0ull;
+            }
+            for (int t = threadIdx.x; t < nw * nrows; t += blockDim.x) {
+                const int ry = t / nw, w = w0 + (t - ry * nw);
+                const int y = yb + ry;
+                uint64_t word = bits[(size_t)y * words_per_row + w];
+                while (word) {
+                    const int bit = __ffsll((long long)word) - 1;
+                    word &= word - 1;
+                    const int x = (w << 6) + bit;
+                    const unsigned lin = (unsigned)(y * out_w + x);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float dx = (float)(x + 1) - px[k], dy = (float)(y + 1) - py[k];
+                        const float d = dx * dx + dy * dy;
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | lin;
+                        b[k] = key < b[k] ? key : b[k];
+                    }
+                }
+            }
+            __syncthreads();                    // best[] of the previous group has been consumed
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                unsigned long long v = b[k];
+                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(v, o); v = other < v ? other : v; }
+                if (lane == 0) best[wave][k] = v;
+            }
+            __syncthreads();
+            if (threadIdx.x < 8) {
+                const int j = jg + threadIdx.x;
+                if (j < j1 && cent[j * 2] >= 0) {
+                    unsigned long long v = best[0][threadIdx.x];
+                    for (int q = 1; q < 4; ++q) v = best[q][threadIdx.x] < v ? best[q][threadIdx.x] : v;
+                    if (v != ~0ull) atomicMin(keys + (size_t)i * kd + (j - j0), v);
+                }
             }
         }
-        for (int k = 32; k > 0; k >>= 1) { const unsigned long long other = __shfl_xor(b, k); b = other < b ? other : b; }
-        __syncthreads();                 // best[] of the previous pair has been consumed
-        if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6] = b;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int k = 1; k < 4; ++k) b = best[k] < b ? best[k] : b;
-            if (b == ~0ull) { o[0] = -1; o[1] = -1; }
-            else {
-                const unsigned lin = (unsigned)(b & 0xffffffffu);
-                o[0] = (int)(lin % (unsigned)out_w) + 1;
-                o[1] = (int)(lin / (unsigned)out_w) + 1;
-            }
+    }
+}
+
+__global__ void closest_init(unsigned long long* __restrict__ keys, const int* __restrict__ total, int n_max, int kd) {
+    const int n = *total < n_max ? *total : n_max;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n * kd; t += gridDim.x * blockDim.x) keys[t] = ~0ull;
+}
+
+__global__ void closest_finalize(const unsigned long long* __restrict__ keys, const int* __restrict__ total, int n_max, int kd,
+                                 int out_w, int* __restrict__ closest) {
+    const int n = *total < n_max ? *total : n_max;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n * kd; t += gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[t];
+        if (k == ~0ull) { closest[t * 2] = -1; closest[t * 2 + 1] = -1; }
+        else {
+            const unsigned lin = (unsigned)(k & 0xffffffffu);
+            closest[t * 2] = (int)(lin % (unsigned)out_w) + 1;
+            closest[t * 2 + 1] = (int)(lin / (unsigned)out_w) + 1;
         }
     }
 }
@@ -251,7 +323,6 @@ int apse_k_closest_single(const uint64_t* bits, int out_h, int out_w, int words_
 int apse_k_mask_paste(const PasteParams* p, int n_max, int* cent, int* mass, hipStream_t s) {
     if (n_max <= 0) return APSE_OK;
     if (p->M > 32) return APSE_E_INVALID;
-    hipMemsetAsync(p->sums, 0, (size_t)n_max * 3 * sizeof(unsigned long long), s);
     hipLaunchKernelGGL(det_postprocess, dim3((n_max + 63) / 64), dim3(64), 0, s, *p, n_max);
     hipLaunchKernelGGL(paste_masks, dim3(PASTE_BLOCKS), dim3(256), 0, s, *p, n_max);
     hipLaunchKernelGGL(mask_centroids, dim3((n_max + 63) / 64), dim3(64), 0, s, p->sums, p->total, n_max, cent, mass);
@@ -259,10 +330,13 @@ int apse_k_mask_paste(const PasteParams* p, int n_max, int* cent, int* mass, hip
 }
 int apse_k_closest_points(const uint64_t* bits, const int* rect, const int* valid, const int* cent, const int* img,
                           const int* offset, const int* total, int n_max, int kd, int out_h, int out_w, int words_per_row,
-                          int* closest, hipStream_t s) {
+                          int* closest, unsigned long long* keys, hipStream_t s) {
     if (n_max <= 0) return APSE_OK;
-    hipLaunchKernelGGL(closest_points, dim3(n_max * kd < 1024 ? n_max * kd : 1024), dim3(256), 0, s, bits, rect, valid, cent, img, offset, total, kd, out_h,
-                       out_w, words_per_row, closest);
+    const int nb = (n_max * kd + 255) / 256;
+    hipLaunchKernelGGL(closest_init, dim3(nb < 64 ? nb : 64), dim3(256), 0, s, keys, total, n_max, kd);
+    hipLaunchKernelGGL(closest_points, dim3(1024), dim3(256), 0, s, bits, rect, valid, cent, img, offset, total, n_max, kd, out_h,
+                       out_w, words_per_row, keys);
+    hipLaunchKernelGGL(closest_finalize, dim3(nb < 64 ? nb : 64), dim3(256), 0, s, keys, total, n_max, kd, out_w, closest);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_bits_to_dense(const uint64_t* bits, const int* rect4, int out_h, int out_w, int words_per_row, uint8_t* dense,

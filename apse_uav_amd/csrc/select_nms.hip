@@ -77,13 +77,18 @@ struct TopkJob {
     int dst_count;         // min(pre_topk, total)
 };
 
-// lists: [B][nslots][1024] u64
+// lists: [B][nslots][1024] u64.  kind 0: sort one 4096-element chunk of raw logits (bitonic, LDS).
+// kind 1: merge up to four sorted lists by rank (position + binary-search counts in the other lists):
+// no sort, no barriers after the load.  `zero_word` (stage 0 only): image b's max-coordinate cell is
+// cleared here so the decode kernel's atomicMax needs no separate memset.
 __global__ __launch_bounds__(1024) void rpn_topk_stage(const RpnLevels* __restrict__ Lp, const TopkJob* __restrict__ jobs,
-                                                       uint64_t* __restrict__ lists, int nslots) {
+                                                       uint64_t* __restrict__ lists, int nslots,
+                                                       uint32_t* __restrict__ zero_word) {
     __shared__ uint64_t a[TK_N];
     const TopkJob* job = jobs + blockIdx.x;
     const int b = blockIdx.y, tid = threadIdx.x;
     uint64_t* pool = lists + (size_t)b * nslots * 1024;
+    if (zero_word && blockIdx.x == 0 && tid == 0) zero_word[b] = 0u;
     if (job->kind == 0) {
         const RpnLevel* lv = &Lp->lv[job->level];
         const int head_ld = Lp->head_ld;
@@ -98,18 +103,32 @@ __global__ __launch_bounds__(1024) void rpn_topk_stage(const RpnLevels* __restri
             }
             a[i] = k;
         }
+        __syncthreads();
+        bitonic_sort_lds<TK_N, 1024>(a, tid);
+        if (tid < job->dst_count) pool[(size_t)job->dst * 1024 + tid] = a[tid];
     } else {
         const int ns = job->nsrc;
-        for (int i = tid; i < TK_N; i += 1024) {
-            const int s = i >> 10, r = i & 1023;
-            uint64_t k = ~0ull;
-            if (s < ns && r < job->src_count[s]) k = pool[(size_t)job->src[s] * 1024 + r];
-            a[i] = k;
+        int cnt[4];
+        for (int s = 0; s < 4; ++s) cnt[s] = s < ns ? job->src_count[s] : 0;
+        for (int s = 0; s < ns; ++s)
+            if (tid < cnt[s]) a[s * 1024 + tid] = pool[(size_t)job->src[s] * 1024 + tid];
+        __syncthreads();
+        const int K = job->dst_count;
+        uint64_t* dst = pool + (size_t)job->dst * 1024;
+        for (int s = 0; s < ns; ++s) {
+            if (tid >= cnt[s]) continue;
+            const uint64_t key = a[s * 1024 + tid];
+            int rank = tid;
+            for (int o = 0; o < ns; ++o) {
+                if (o == s) continue;
+                int lo = 0, hi = cnt[o];
+                const uint64_t* ko = a + o * 1024;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (ko[mid] < key) lo = mid + 1; else hi = mid; }
+                rank += lo;
+            }
+            if (rank < K) dst[rank] = key;
         }
     }
-    __syncthreads();
-    bitonic_sort_lds<TK_N, 1024>(a, tid);
-    if (tid < job->dst_count) pool[(size_t)job->dst * 1024 + tid] = a[tid];
 }
 
 // Decode the selected anchors of every level: Box2BoxTransform.apply_deltas (weights 1,1,1,1),
@@ -315,9 +334,11 @@ __global__ __launch_bounds__(1024) void rank_merge(const float* __restrict__ box
                                                    int n_total, const int* __restrict__ keep_idx,
                                                    const int* __restrict__ keep_cnt, int ncat, int K,
                                                    float* __restrict__ out_boxes, float* __restrict__ out_scores,
-                                                   int* __restrict__ out_entry, int* __restrict__ out_count) {
+                                                   int* __restrict__ out_entry, int* __restrict__ out_count,
+                                                   uint32_t* __restrict__ zero_word) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);      // [ncat][NMS_MAX]
+    if (zero_word && threadIdx.x == 0) zero_word[blockIdx.x] = 0u;      // next stage's max-coordinate cell
     __shared__ int cnt[8];
     const int b = blockIdx.x, tid = threadIdx.x;
     boxes += (size_t)b * n_total * 4;
@@ -440,9 +461,9 @@ __global__ void pack_detections(const float* __restrict__ det_boxes, const float
 
 extern "C" {
 int apse_k_rpn_topk_stage(const RpnLevels* L_dev, const TopkJob* jobs_dev, int njobs, uint64_t* lists, int nslots, int B,
-                          hipStream_t s) {
+                          uint32_t* zero_word, hipStream_t s) {
     if (njobs <= 0) return APSE_OK;
-    hipLaunchKernelGGL(rpn_topk_stage, dim3(njobs, B), dim3(1024), 0, s, L_dev, jobs_dev, lists, nslots);
+    hipLaunchKernelGGL(rpn_topk_stage, dim3(njobs, B), dim3(1024), 0, s, L_dev, jobs_dev, lists, nslots, zero_word);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_rpn_decode(const RpnLevels* L_dev, int pre_topk, const uint64_t* lists, int nslots, const int* final_slot_dev,
@@ -482,8 +503,8 @@ int apse_k_nms_percat(const float* boxes, const float* scores, const int* valid,
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_rank_final(const float* boxes, const float* scores, int n_total, const int* keep_idx, const int* keep_cnt,
-                      int ncat, int K, float* out_boxes, float* out_scores, int* out_entry, int* out_count, int B,
-                      hipStream_t s) {
+                      int ncat, int K, float* out_boxes, float* out_scores, int* out_entry, int* out_count,
+                      uint32_t* zero_word, int B, hipStream_t s) {
     static bool done = false;
     if (!done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_merge), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -492,7 +513,7 @@ int apse_k_rank_final(const float* boxes, const float* scores, int n_total, cons
     }
     if (ncat > 8) return APSE_E_INVALID;
     hipLaunchKernelGGL(rank_merge, dim3(B), dim3(1024), (size_t)ncat * NMS_MAX * 8, s, boxes, scores, n_total, keep_idx, keep_cnt,
-                       ncat, K, out_boxes, out_scores, out_entry, out_count);
+                       ncat, K, out_boxes, out_scores, out_entry, out_count, zero_word);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_box_candidates(const float* pred, int ld, int K, const float* props, const int* prop_cnt, int P, float img_h,

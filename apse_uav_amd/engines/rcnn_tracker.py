@@ -72,11 +72,12 @@ class RcnnTracker:
     def next_record(self, record):
         """Same association driven by a per-frame record (FrameResults.record)."""
         self.frame_count += 1
-        return self._finish_frame(instances_from_record(record, self.image_size, self.device), None)
+        return self._finish_frame(instances_from_record(record, self.image_size, self.device), None, host_replay=True)
 
-    def _finish_frame(self, detections, backbone_features):
+    def _finish_frame(self, detections, backbone_features, host_replay=False):
         self._last_record = getattr(detections, "_record", None)
         self._obj_det = {}
+        self._host_replay = host_replay
         self.associate_detections_to_objects(detections, backbone_features=backbone_features, metric='embeddings')
         self.objects.delete_undetected_objects(self.OBJECT_UNDETECTED_FRAMES_TH)
         if 'objects' in self.DISPLAY_INFO: print(self.objects)
@@ -93,7 +94,11 @@ class RcnnTracker:
         if len(detections) > 0:
             rec = getattr(detections, "_record", None)
             if rec is not None:
-                detection_embeddings = torch.from_numpy(rec["embeddings"]).to(self.device)
+                # embeddings already computed by the fused GPU stage; kept on the host: the sequential
+                # association (this method) is host work, also on rank 0 of a sharded run
+                detection_embeddings = torch.from_numpy(np.ascontiguousarray(rec["embeddings"]))
+                if not getattr(self, "_host_replay", False):
+                    detection_embeddings = detection_embeddings.to(self.device)     # next_frame: distance matrix on the GPU
             else:
                 rois = self.get_features_rois(detections, backbone_features, crop_features=self.crop_features)
                 detection_embeddings = self.association_head(rois)
@@ -140,7 +145,13 @@ class RcnnTracker:
         return out.permute(0, 3, 1, 2)
 
     def calculate_distance_matrix(self, detection_embeddings):
-        """O x N squared L2 distances (rcnn_tracker.py:192-221) on the GPU."""
+        """O x N squared L2 distances (rcnn_tracker.py:192-221).  Device embeddings -> HIP kernel; host
+        embeddings (record path: the GPU already produced them, the replay is pure host) -> numpy f32."""
+        if not detection_embeddings.is_cuda:
+            obj = np.stack([np.asarray(e, np.float32) for e in self.objects.embeddings])
+            det = detection_embeddings.numpy()
+            diff = obj[:, None, :] - det[None, :, :]
+            return torch.from_numpy((diff * diff).sum(axis=2, dtype=np.float32))
         obj = torch.stack([e.to(self.device) for e in self.objects.embeddings]).contiguous()
         det = detection_embeddings.to(self.device).contiguous()
         out = torch.empty((obj.shape[0], det.shape[0]), device=self.device, dtype=torch.float32)
