@@ -177,3 +177,38 @@ def test_bf16_mode_vs_bf16_oracle(setup, logdir):
             matched += 1
     _log(logdir, "bf16/matched", dict(matched=matched, n=n))
     assert matched >= min(n, rn) - 2
+
+
+def test_no_detections_and_full_list(setup, logdir):
+    """Edge cases of the packed detection list: zero detections (threshold never met) and the 100-detection
+    cap (threshold ~0): both must run, agree with the oracle on the count and keep the tracker/CSV logic sane."""
+    from PIL import Image
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from apse_uav_amd.utils import csv_log
+    from oracle.detector import DetectorOracle
+    frame = setup["seq"].frame(0)
+    img = np.asarray(Image.fromarray(frame).resize((setup["iw"], setup["ih"]), Image.BILINEAR))
+    x = torch.as_tensor(img.astype("float32").transpose(2, 0, 1))
+    for thr, expect in ((0.9999, "zero"), (0.02, "cap")):
+        cfg = _cfg()
+        cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST = thr
+        tr = RcnnTracker(cfg, FRAME, setup["asd"], detector_state=setup["sd"])
+        objs = tr.next_frame(frame)
+        post = DetectorOracle(setup["sd"], dict(depth_blocks=BLOCKS, min_size=256, max_size=448, score_thresh=thr)).inference(
+            x, FRAME[0], FRAME[1])
+        n, rn = len(objs), int(post["boxes"].shape[0])
+        _log(logdir, "edge/" + expect, dict(n=n, ref_n=rn))
+        assert n == rn
+        if expect == "zero":
+            assert n == 0 and tr.log_line(objs, 1, 0) == ("", 0)
+            objs2 = tr.next_frame(frame)                       # still nothing tracked, ids untouched
+            assert len(objs2) == 0 and tr.objects.get_new_id() == 1
+        else:
+            assert n == 100 and list(objs.ids) == list(range(1, 101))
+            assert torch.equal(torch.stack([c for c in objs.pred_classes]), post["classes"])
+            got = torch.stack([b.tensor[0] for b in objs.pred_boxes])
+            assert float((got - post["boxes"]).abs().max()) < 5e-2
+            line, hi = tr.log_line(objs, 1, 0)
+            assert hi == 100 and len(line.split(",")) == 1 + 4 * 100
+            objs2 = tr.next_frame(frame)                       # same frame again: every object re-associated
+            assert sorted(objs2.ids) == list(range(1, 101))
