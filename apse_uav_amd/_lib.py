@@ -42,7 +42,7 @@ class ResultsLayout(C.Structure):
 
 class ConvDesc(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "relu", "res_mode",
-                                       "cfg", "splitk", "prec")]
+                                       "cfg", "splitk", "prec", "fuse_reduce")]
 
 
 _lib = None

@@ -26,6 +26,7 @@ struct ConvParams {
     const float* res;     // residual (res_mode != 0)
     float* y;
     float* ws;            // split-K partials [splitk][M][Cout_ws]
+    int* tile_cnt;        // per-tile arrival counters (zero between launches) -> in-launch split-K reduction; nullptr -> reduce kernel
     const int* m_count;   // optional device int: number of valid items; M_eff = min(M, *m_count * m_per_item)
     int m_per_item;
     int B, H, W, cin_log2;

@@ -206,54 +206,99 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
         constexpr int RPP = 256 / C4;              // rows covered per pass
         const int c4 = tid % C4;
         const int n = n0 + c4 * 4;
-        const int ld_out = direct ? p.y_ld : p.Cout;
-        bool vec_ok;
-        if (!direct) vec_ok = (p.Cout & 3) == 0;
-        else if (p.out_mode == 1) vec_ok = (p.cdec & 3) == 0;
-        else vec_ok = ((ld_out & 3) == 0) && ((p.y_coff & 3) == 0) && (p.y_coff + n + 4 <= ld_out);
+        bool vec_direct;
+        if (p.out_mode == 1) vec_direct = (p.cdec & 3) == 0;
+        else vec_direct = ((p.y_ld & 3) == 0) && ((p.y_coff & 3) == 0) && (p.y_coff + n + 4 <= p.y_ld);
+        const bool vec_ws = (p.Cout & 3) == 0;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        int co = n, g = 0;
         if (n < p.Cout) {
-            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-            int co = n, g = 0;
-            if (direct) {
-                if (p.out_mode == 1) { g = n / p.cdec; co = n - g * p.cdec; }
-                if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);     // bias is padded to Cout_p
-            }
-            for (int r = tid / C4; r < BM; r += RPP) {
-                const int m = m0 + r;
-                if (m >= M) break;
-                f32x4 val = *reinterpret_cast<const f32x4*>(Cs + r * LDC + c4 * 4);
-                float* dst;
-                if (!direct) {
-                    dst = p.ws + ((size_t)z * p.M + m) * p.Cout + n;
-                } else {
-                    val += bias4;
-                    if (p.out_mode == 0) {
-                        if (p.res_mode == 1) {
-                            val += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + n);
-                        } else if (p.res_mode == 2) {
-                            const int b = m / ohw;
-                            const int rem = m - b * ohw;
-                            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                            const int hw2 = (p.OH >> 1) * (p.OW >> 1);
-                            val += *reinterpret_cast<const f32x4*>(
-                                p.res + ((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n);
-                        }
-                        dst = p.y + (size_t)m * p.y_ld + p.y_coff + n;
-                    } else {
-                        const int b = m / ohw;
-                        const int rem = m - b * ohw;
-                        const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                        dst = p.y + (((size_t)b * 2 * p.OH + 2 * oy + (g >> 1)) * (2 * p.OW) + 2 * ox + (g & 1)) * p.cdec + co;
-                    }
-                    if (p.relu) {
-                        val[0] = val[0] > 0.f ? val[0] : 0.f; val[1] = val[1] > 0.f ? val[1] : 0.f;
-                        val[2] = val[2] > 0.f ? val[2] : 0.f; val[3] = val[3] > 0.f ? val[3] : 0.f;
-                    }
+            if (p.out_mode == 1) { g = n / p.cdec; co = n - g * p.cdec; }
+            if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);     // bias is padded to Cout_p
+        }
+        // bias + residual + ReLU + store of one float4 of output row m (the fused epilogue proper)
+        auto finish = [&](f32x4 val, int m) {
+            val += bias4;
+            float* dst;
+            if (p.out_mode == 0) {
+                if (p.res_mode == 1) {
+                    val += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + n);
+                } else if (p.res_mode == 2) {
+                    const int b = m / ohw;
+                    const int rem = m - b * ohw;
+                    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                    const int hw2 = (p.OH >> 1) * (p.OW >> 1);
+                    val += *reinterpret_cast<const f32x4*>(
+                        p.res + ((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n);
                 }
-                if (vec_ok) {
-                    *reinterpret_cast<f32x4*>(dst) = val;
-                } else {
-                    for (int k = 0; k < 4; ++k) if (n + k < p.Cout) dst[k] = val[k];
+                dst = p.y + (size_t)m * p.y_ld + p.y_coff + n;
+            } else {
+                const int b = m / ohw;
+                const int rem = m - b * ohw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                dst = p.y + (((size_t)b * 2 * p.OH + 2 * oy + (g >> 1)) * (2 * p.OW) + 2 * ox + (g & 1)) * p.cdec + co;
+            }
+            if (p.relu) {
+                val[0] = val[0] > 0.f ? val[0] : 0.f; val[1] = val[1] > 0.f ? val[1] : 0.f;
+                val[2] = val[2] > 0.f ? val[2] : 0.f; val[3] = val[3] > 0.f ? val[3] : 0.f;
+            }
+            if (vec_direct) {
+                *reinterpret_cast<f32x4*>(dst) = val;
+            } else {
+                for (int k = 0; k < 4; ++k) if (n + k < p.Cout) dst[k] = val[k];
+            }
+        };
+        if (direct) {
+            if (n < p.Cout)
+                for (int r = tid / C4; r < BM; r += RPP) {
+                    const int m = m0 + r;
+                    if (m >= M) break;
+                    finish(*reinterpret_cast<const f32x4*>(Cs + r * LDC + c4 * 4), m);
+                }
+        } else {
+            // split-K: this block's partial tile goes to its slab of the workspace
+            if (n < p.Cout)
+                for (int r = tid / C4; r < BM; r += RPP) {
+                    const int m = m0 + r;
+                    if (m >= M) break;
+                    const f32x4 val = *reinterpret_cast<const f32x4*>(Cs + r * LDC + c4 * 4);
+                    float* dst = p.ws + ((size_t)z * p.M + m) * p.Cout + n;
+                    if (vec_ws) *reinterpret_cast<f32x4*>(dst) = val;
+                    else for (int k = 0; k < 4; ++k) if (n + k < p.Cout) dst[k] = val[k];
+                }
+            if (p.tile_cnt) {
+                // In-launch reduction by the last-arriving K-slice of this tile (cdna_hip_programming.md, section 5
+                // "In-launch split-K reduction"): plain slab stores -> every wave drains its stores -> barrier ->
+                // one lane: agent-scope release, arrival ticket; the block that draws splitk-1 acquires and sums
+                // the slabs in the fixed order z = 0..splitk-1 (bitwise reproducible, independent of arrival order).
+                int* flag = reinterpret_cast<int*>(Cs + BM * LDC);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const int ticket = __hip_atomic_fetch_add(p.tile_cnt + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int last = ticket == p.splitk - 1;
+                    if (last) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(p.tile_cnt + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+                    }
+                    *flag = last;
+                }
+                __syncthreads();
+                if (*flag && n < p.Cout) {
+                    for (int r = tid / C4; r < BM; r += RPP) {
+                        const int m = m0 + r;
+                        if (m >= M) break;
+                        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                        const float* src = p.ws + (size_t)m * p.Cout + n;
+                        for (int zz = 0; zz < p.splitk; ++zz) {
+                            if (vec_ws) val += *reinterpret_cast<const f32x4*>(src + (size_t)zz * p.M * p.Cout);
+                            else for (int k = 0; k < 4; ++k) if (n + k < p.Cout) val[k] += src[(size_t)zz * p.M * p.Cout + k];
+                        }
+                        finish(val, m);
+                    }
                 }
             }
         }
@@ -305,7 +350,7 @@ template <int WM, int WN, int TM, int TN, int KS>
 static int launch_cfg(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
-    const size_t lds_stage = (size_t)2 * KS * (BM + BN) * 32 * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+    const size_t lds_stage = (size_t)2 * KS * (BM + BN) * 32 * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float) + 16;
     const size_t lds = lds_stage > lds_c ? lds_stage : lds_c;
     static bool attr_done = false;
     if (!attr_done) {
@@ -315,7 +360,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t s) {
     }
     const int grid_x = (p.m_count && tiles > 1024) ? 1024 : tiles;
     hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, KS>), dim3(grid_x, p.splitk), dim3(256), lds, s, p);
-    if (p.splitk > 1) {
+    if (p.splitk > 1 && !p.tile_cnt) {
         const size_t total = (size_t)p.M * p.Cout;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
@@ -329,7 +374,7 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s) {
     if (p.res_mode != 0 && (p.Cout & 3) != 0) return APSE_E_INVALID;      // residual rows are read as float4
     if (p.prec == 1) {
         int rc = apse_launch_conv_bf16(p, cfg, s);
-        if (rc == APSE_OK && p.splitk > 1) {
+        if (rc == APSE_OK && p.splitk > 1 && !p.tile_cnt) {
             const size_t total = (size_t)p.M * p.Cout;
             int blocks = (int)((total + 255) / 256);
             if (blocks > 4096) blocks = 4096;

@@ -81,7 +81,7 @@ struct apse_ctx {
     std::vector<void*> allocs;
     std::map<std::string, Tens> t;
     std::vector<Step> backbone, rpnhead, boxhead, maskhead, embedfc;
-    float* ws = nullptr; size_t ws_floats = 0;
+    float* ws = nullptr; size_t ws_floats = 0; int* tile_cnt = nullptr;
     // resize tables
     int *hb = nullptr, *hc = nullptr, *vb = nullptr, *vc = nullptr; int hk = 0, vk = 0; uint8_t* rs_tmp = nullptr;
     // rpn
@@ -314,6 +314,10 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
             p.B = batch * st.c.b_mult;
             p.M = p.B * p.OH * p.OW;
             p.ws = c->ws;
+            // In-launch split-K reduction (last arriver) measured SLOWER here than the separate reduce kernel
+            // (f32 132 -> 111 FPS): 64-512 KB of slabs per tile and an agent-scope release (L2 write-back) per
+            // block; it stays available through apse_conv_desc.fuse_reduce for small slabs.
+            p.tile_cnt = nullptr;
             p.m_count = nullptr; p.m_per_item = p.OH * p.OW;
             int cfg = st.c.cfg;
             if (st.c.count_kind == 2) {
@@ -593,6 +597,7 @@ static int build_plan(apse_ctx* c) {
         c->ws = dalloc<float>(c, c->ws_floats, false);
         if (!c->ws) return fail(c, APSE_E_NOMEM, "split-K workspace alloc");
     }
+    c->tile_cnt = dalloc<int>(c, 65536);        // zero-initialised; every launch leaves it zero
     c->rs_tmp = dalloc<uint8_t>(c, (size_t)B * g.frame_h * g.image_w * 3, false);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail(c, APSE_E_HIP, std::string("plan build: ") + hipGetErrorString(e));
@@ -998,6 +1003,11 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
     if (sk > p.steps_total) sk = p.steps_total;
     p.splitk = sk;
     if (sk > 1 && (size_t)sk * p.M * p.Cout * sizeof(float) > ws_bytes) return APSE_E_INVALID;
+    if (sk > 1 && d->fuse_reduce) {
+        static int* cnt = nullptr;
+        if (!cnt) { if (hipMalloc(reinterpret_cast<void**>(&cnt), 65536 * sizeof(int)) != hipSuccess) return APSE_E_NOMEM; hipMemset(cnt, 0, 65536 * sizeof(int)); }
+        p.tile_cnt = cnt;
+    }
     return apse_launch_conv(p, cfg, (hipStream_t)stream);
 }
 

@@ -45,6 +45,10 @@ def main():
                     help="HIP-event pairs around every convolution launch on every n-th timed step (each pair costs "
                          "~5 us of stream time, ~1.5 ms per fully instrumented frame)")
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="frames in flight per GPU: >1 runs consecutive steps on separate HIP streams / contexts so the "
+                         "small-grid layers of one frame overlap with the next frame's (detection is stateless per "
+                         "frame; the host association still consumes frames in order)")
     ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"],
                     help="f32 = exact-f32 MFMA (reference numerics, BASELINE configs[1]); bf16 = bf16 matrix cores with "
                          "f32 accumulate/storage for the bulk GEMMs (configs[2]/[4] style)")
@@ -95,12 +99,30 @@ def main():
     lib = _lib.load()
     records = []
 
-    def step(i, timed):
-        idx = [(i * B + k) % nres for k in range(B)]
+    # optional software pipeline over frames: depth contexts on depth streams (weights replicated)
+    depth = max(1, args.pipeline)
+    models = [model]
+    if depth > 1:
+        from apse_uav_amd.networks.track_rcnn import TrackRCNN
+        for _ in range(depth - 1):
+            m2 = TrackRCNN(cfg)
+            m2.load_state_dict(sd)
+            m2.attach_association_head(tracker.association_head)
+            models.append(m2)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(depth - 1)]
+
+    def submit(i):
+        k = i % depth
+        idx = [(i * B + j) % nres for j in range(B)]
         batch = frames[idx] if B > 1 else frames[idx[0]:idx[0] + 1]
-        model.preprocess_frames(batch)
-        model.run(B)
-        res = model.read(B)                       # D2H of the results block + stream sync
+        with torch.cuda.stream(streams[k]):
+            models[k].preprocess_frames(batch)
+            models[k].run(B)
+
+    def collect(i, timed):
+        k = i % depth
+        with torch.cuda.stream(streams[k]):
+            res = models[k].read(B)                   # D2H of the results block + sync of that stream
         for b in range(B):
             rec = res.record(b)
             if world == 1:
@@ -109,6 +131,10 @@ def main():
             elif timed:
                 records.append(rec)
         return res
+
+    def step(i, timed):
+        submit(i)
+        return collect(i, timed)
 
     for i in range(args.warmup):
         res = step(i, False)
@@ -121,16 +147,27 @@ def main():
     P_sum = N_sum = 0
     n_instr = 0
     t0 = time.perf_counter()
+    def account(res):
+        nonlocal P_sum, N_sum
+        P_sum += int(res.prop_count[:B].sum())
+        N_sum += res.total
+
+    inflight = []          # (step index, submit time)
     for i in range(args.steps):
         if not args.no_events:
             on = i % max(args.event_every, 1) == 0
             n_instr += int(on)
-            lib.apse_profile(model._ctx, 1 if on else 0)
-        ts = time.perf_counter()
-        res = step(args.warmup + i, True)
+            lib.apse_profile(models[i % depth]._ctx, 1 if on else 0)
+        inflight.append((args.warmup + i, time.perf_counter()))
+        submit(args.warmup + i)
+        if len(inflight) == depth:
+            j, ts = inflight.pop(0)
+            account(collect(j, True))
+            lat.append(time.perf_counter() - ts)
+    while inflight:
+        j, ts = inflight.pop(0)
+        account(collect(j, True))
         lat.append(time.perf_counter() - ts)
-        P_sum += int(res.prop_count[:B].sum())
-        N_sum += res.total
     if dist is not None:
         allrec = gather_records(records, rank, world, dev)      # the single exchange step (RCCL over xGMI)
         if rank == 0:
@@ -147,10 +184,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     import ctypes as C
-    prof = (C.c_double * 24)()
-    lib.apse_profile_read(model._ctx, C.byref(prof), 1)
-    lib.apse_profile(model._ctx, 0)
-    prof = np.array(list(prof)).reshape(8, 3)
+    prof = np.zeros((8, 3))
+    for m in models:
+        pr = (C.c_double * 24)()
+        lib.apse_profile_read(m._ctx, C.byref(pr), 1)
+        lib.apse_profile(m._ctx, 0)
+        prof += np.array(list(pr)).reshape(8, 3)
 
     if rank == 0:
         frames_total = args.steps * B * world
@@ -168,7 +207,7 @@ def main():
             "p50_ms_per_frame": round(1000.0 * float(np.median(lat)) / B, 3),
             "config": {"workload": "static synthetic 3840x2160 sequence, batch=%d %s, Mask R-CNN R-%s-FPN, %d GPU(s), "
                                    "frames sharded per rank" % (B, args.dtype, "101" if blocks == (3, 4, 23, 3) else str(blocks), world),
-                       "frame": "%dx%d" % (W, H), "batch_per_gpu": B, "proposals_per_frame": P_sum / max(args.steps * B, 1),
+                       "frame": "%dx%d" % (W, H), "batch_per_gpu": B, "frames_in_flight": depth, "proposals_per_frame": P_sum / max(args.steps * B, 1),
                        "detections_per_frame": N_sum / max(args.steps * B, 1),
                        "gflop_per_frame_algorithmic": round(flops_frame / 1e9, 2)},
             "roofline": {"bound": "mfma", "kernel": CFG_NAMES[dom], "achieved": round(achieved, 3),

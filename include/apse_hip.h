@@ -150,6 +150,7 @@ typedef struct apse_conv_desc {
     int cfg;                /* -1 auto, else tile config 0..3 */
     int splitk;             /* 0 auto */
     int prec;               /* 0 f32 MFMA, 1 bf16 MFMA (operands rounded at LDS staging, f32 accumulate) */
+    int fuse_reduce;        /* split-K: 1 = last-arriving block reduces in the launch, 0 = separate reduce kernel */
 } apse_conv_desc;
 size_t apse_conv_packed_elems(const apse_conv_desc* d);
 /* OIHW host filter (+ optional per-channel scale) -> packed host filter for apse_conv2d. */

@@ -15,7 +15,7 @@ def to_nhwc(x, cpad=None):
 
 
 def hip_conv2d(x_nchw, w_oihw, bias=None, stride=1, pad=0, relu=False, residual=None, res_mode=0, cfg=-1, splitk=0,
-               scale=None, prec=0):
+               scale=None, prec=0, fuse=0):
     """x: CPU NCHW f32; returns CPU NCHW f32 computed by apse_conv2d on cuda:0."""
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -27,7 +27,7 @@ def hip_conv2d(x_nchw, w_oihw, bias=None, stride=1, pad=0, relu=False, residual=
     d = _lib.ConvDesc()
     d.B, d.H, d.W, d.Cin = B, H, W, cin_p
     d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, KH, KW, stride, pad
-    d.relu, d.res_mode, d.cfg, d.splitk, d.prec = int(relu), res_mode, cfg, splitk, prec
+    d.relu, d.res_mode, d.cfg, d.splitk, d.prec, d.fuse_reduce = int(relu), res_mode, cfg, splitk, prec, fuse
     packed = np.zeros(lib.apse_conv_packed_elems(C.byref(d)), np.float32)
     w = np.ascontiguousarray(w_oihw.numpy(), np.float32)
     sc = None if scale is None else np.ascontiguousarray(scale.numpy(), np.float32)

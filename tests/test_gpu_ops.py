@@ -94,6 +94,25 @@ def test_conv2d_bf16_parity(case, logdir):
     assert st["rel_to_max"] < 2e-5, st          # products of bf16 values are exact in f32: order-of-sum noise only
 
 
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("shape", [(1, 512, 12, 14, 128, 3, 5, 1), (1, 256, 48, 84, 256, 3, 8, 0), (3, 256, 10, 10, 128, 10, 64, 1),
+                                   (1, 1024, 24, 42, 512, 1, 4, 1)])
+def test_conv2d_fused_splitk(shape, prec, logdir):
+    """Split-K with the in-launch reduction (last-arriving K-slice sums the slabs): must equal the separate
+    reduce-kernel path bit for bit (same fixed summation order), run repeatedly on a busy GPU."""
+    from hip_helpers import hip_conv2d
+    B, Cin, H, W, Cout, K, sk, cfg = shape
+    g = torch.Generator().manual_seed(Cin + Cout + sk)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    pad = 1 if K == 3 else 0
+    ref = hip_conv2d(x, w, b, 1, pad, True, None, 0, cfg, sk, prec=prec, fuse=0)
+    for rep in range(6):
+        out = hip_conv2d(x, w, b, 1, pad, True, None, 0, cfg, sk, prec=prec, fuse=1)
+        assert torch.equal(out, ref), (rep, float((out - ref).abs().max()))
+
+
 def test_maxpool(logdir):
     from apse_uav_amd import _lib
     from hip_helpers import to_nhwc

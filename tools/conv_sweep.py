@@ -15,13 +15,15 @@ SHAPES = [  # name, B, H, W, Cin, Cout, K, stride, pad
     ("res2.c3", 1, 192, 336, 64, 256, 1, 1, 0), ("res2.c2", 1, 192, 336, 64, 64, 3, 1, 1), ("lat2", 1, 192, 336, 256, 256, 1, 1, 0),
     ("out3", 1, 96, 168, 256, 256, 3, 1, 1), ("fc1", 1000, 7, 7, 256, 1024, 7, 1, 0), ("mask8", 8, 14, 14, 256, 256, 3, 1, 1),
 ]
-if len(sys.argv) > 1:
-    SHAPES = [s for s in SHAPES if s[0] in sys.argv[1:]]
+PREC = 1 if "--bf16" in sys.argv else 0
+names = [a for a in sys.argv[1:] if not a.startswith("--")]
+if names:
+    SHAPES = [s for s in SHAPES if s[0] in names]
 dev = "cuda"
 for (name, B, H, W, Cin, Cout, K, st, pad) in SHAPES:
     d = _lib.ConvDesc()
     d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad = B, H, W, Cin, Cout, K, K, st, pad
-    d.relu, d.res_mode = 1, 0
+    d.relu, d.res_mode, d.prec = 1, 0, PREC
     OH = (H + 2 * pad - K) // st + 1
     OW = (W + 2 * pad - K) // st + 1
     M = B * OH * OW
@@ -35,7 +37,7 @@ for (name, B, H, W, Cin, Cout, K, st, pad) in SHAPES:
     for cfg in (0, 1, 3):
         if cfg == 0 and Cout < 128:
             continue
-        for sk in (1, 2, 3, 4, 6, 8, 16):
+        for sk in (1, 2, 4, 8, 16):
             d.cfg, d.splitk = cfg, sk
             steps = K * ((K * Cin + 31) // 32)
             if sk > max(1, steps // 2):
