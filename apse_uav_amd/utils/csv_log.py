@@ -107,3 +107,23 @@ def read_centroid_data(path):
 def pixel_distance(a, b):
     """aruco_detect.py:483-492 pixel part of calculateDistance."""
     return float(np.sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1])))
+
+
+def calculate_distance(lidar, aruco, bbox, marker_length, msp4, msp):
+    """The consumer's only arithmetic on the CSV values, restated from
+    /root/reference/aruco_detect.py:483-492 ``calculateDistance``: pixel distances from the host's lidar
+    point to the vehicle's marker and to its closest point, converted to metres with the mean marker size
+    in pixels.  Returns (dist_aruco, dist_bbox)."""
+    d_aruco = pixel_distance(lidar[0], aruco[0])
+    d_bbox = pixel_distance(lidar[0], bbox[0])
+    scale = marker_length / ((msp4 + msp) / 2)
+    return d_aruco * scale, d_bbox * scale
+
+
+def dcnn_points(row, vehicle):
+    """Columns of one parsed CSV row the consumer uses (aruco_detect.py:634,665-666,692-693,719-720):
+    vehicle 0 = host centroid [1:3]; vehicles 1..3 = (centroid [5+4k:7+4k], closest point [7+4k:9+4k])."""
+    if vehicle == 0:
+        return (row[1], row[2]), None
+    b = 5 + 4 * (vehicle - 1)
+    return (row[b], row[b + 1]), (row[b + 2], row[b + 3])

@@ -166,3 +166,15 @@ def test_synthetic_sequence_deterministic():
     assert a.dtype == np.uint8 and a.shape == (108, 192, 3) and np.array_equal(a, b)
     s = SyntheticSequence("dynamic", 108, 192)
     assert len(s.boxes(0)) == 4 and len(s.boxes(25)) == 3
+
+
+def test_consumer_distance_step(golden_dir):
+    """aruco_detect.py:483-492 on rows of the shipped CSV: the pixel->metre step downstream of the log."""
+    from apse_uav_amd.utils import csv_log
+    rows = csv_log.read_centroid_data(os.path.join(golden_dir, "static_dcnn_data_head.csv"))
+    host, _ = csv_log.dcnn_points(rows[0], 0)
+    cen, clo = csv_log.dcnn_points(rows[0], 1)
+    assert host == (1911, 966) and cen == (192, 1380) and clo == (365, 1338)
+    da, db = csv_log.calculate_distance([host], [cen], [clo], 0.8, 40.0, 44.0)
+    assert abs(da - np.hypot(1911 - 192, 966 - 1380) * 0.8 / 42.0) < 1e-9
+    assert abs(db - np.hypot(1911 - 365, 966 - 1338) * 0.8 / 42.0) < 1e-9 and db < da
