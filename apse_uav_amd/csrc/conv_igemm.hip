@@ -372,7 +372,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t s) {
 int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s) {
     if (p.M <= 0 || p.Cout <= 0 || p.steps_total <= 0) return APSE_E_INVALID;
     if (p.res_mode != 0 && (p.Cout & 3) != 0) return APSE_E_INVALID;      // residual rows are read as float4
-    if (p.prec == 1) {
+    if (p.prec == 1 || p.prec == 2) {
         int rc = apse_launch_conv_bf16(p, cfg, s);
         if (rc == APSE_OK && p.splitk > 1 && !p.tile_cnt) {
             const size_t total = (size_t)p.M * p.Cout;

@@ -1,4 +1,4 @@
-// Implicit-GEMM convolution, bf16 matrix cores (v_mfma_f32_32x32x16_bf16) with f32 storage (gfx950).
+// Implicit-GEMM convolution, 16-bit matrix cores (v_mfma_f32_32x32x16_bf16 / _f16) with f32 storage (gfx950).
 //
 // Same GEMM view, tiling, LDS swizzle, persistent tile loop, split-K and fused epilogue as
 // conv_igemm.hip; the difference is the operand precision: activations and filters are read as f32
@@ -10,8 +10,13 @@
 // predictor, mask logits, association FC) stay on the exact-f32 kernel.
 #include "apse_common.h"
 
-template <int WM, int WN, int TM, int TN, int KS>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+template <typename ET, int WM, int WN, int TM, int TN, int KS>
 __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
+    typedef ET et8 __attribute__((ext_vector_type(8)));
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int AP = BM / 32;   // staging passes (32 rows x 8 slots of 16 B per pass)
@@ -84,11 +89,11 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
             }
         }
 
-        bf16x8 ra[KS][AP], rb[KS][BP];
+        et8 ra[KS][AP], rb[KS][BP];
         auto cvt8 = [](const f32x4 lo, const f32x4 hi) {
-            bf16x8 r;
-            r[0] = (__bf16)lo[0]; r[1] = (__bf16)lo[1]; r[2] = (__bf16)lo[2]; r[3] = (__bf16)lo[3];
-            r[4] = (__bf16)hi[0]; r[5] = (__bf16)hi[1]; r[6] = (__bf16)hi[2]; r[7] = (__bf16)hi[3];
+            et8 r;
+            r[0] = (ET)lo[0]; r[1] = (ET)lo[1]; r[2] = (ET)lo[2]; r[3] = (ET)lo[3];
+            r[4] = (ET)hi[0]; r[5] = (ET)hi[1]; r[6] = (ET)hi[2]; r[7] = (ET)hi[3];
             return r;
         };
         auto load_step = [&](int sb) {
@@ -117,10 +122,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
                     const int n = n0 + srow + 32 * i;
                     const size_t wo = (size_t)n * w_row + (size_t)r * p.KWCp + q;
                     if (p.w16) {                     // filters pre-rounded to bf16: one 16-byte load per slot
-                        bf16x8 v;
+                        et8 v;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-                        if (qa) v = *reinterpret_cast<const bf16x8*>(p.w16 + wo);
+                        for (int e = 0; e < 8; ++e) v[e] = (ET)0.f;
+                        if (qa) v = *reinterpret_cast<const et8*>(p.w16 + wo);
                         rb[u][i] = v;
                     } else {
                         f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
@@ -138,13 +143,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
                 for (int i = 0; i < AP; ++i) {
                     const int row = srow + 32 * i;
                     const int ps = slot ^ ((row >> 1) & 7);
-                    *reinterpret_cast<bf16x8*>(As + ((buf * KS + u) * BM + row) * 128 + ps * 16) = ra[u][i];
+                    *reinterpret_cast<et8*>(As + ((buf * KS + u) * BM + row) * 128 + ps * 16) = ra[u][i];
                 }
 #pragma unroll
                 for (int i = 0; i < BP; ++i) {
                     const int row = srow + 32 * i;
                     const int ps = slot ^ ((row >> 1) & 7);
-                    *reinterpret_cast<bf16x8*>(Bs + ((buf * KS + u) * BN + row) * 128 + ps * 16) = rb[u][i];
+                    *reinterpret_cast<et8*>(Bs + ((buf * KS + u) * BN + row) * 128 + ps * 16) = rb[u][i];
                 }
             }
         };
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
                 if (sb + 1 < s_end) load_step(sb + 1);
                 // fragments are double-buffered in registers: the ds_read_b128s of chunk c+1 are issued
                 // before the MFMAs of chunk c, so LDS latency hides behind the matrix pipe.
-                bf16x8 af[2][TM], bf[2][TN];
+                et8 af[2][TM], bf[2][TN];
                 auto load_frags = [&](int cc, int fb) {
                     const int u = cc >> 2, c = cc & 3;
                     const char* Ab = As + (buf * KS + u) * BM * 128;
@@ -175,12 +180,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const int row = (wm * TM + i) * 32 + fr;
-                        af[fb][i] = *reinterpret_cast<const bf16x8*>(Ab + row * 128 + ((ls ^ ((row >> 1) & 7)) << 4));
+                        af[fb][i] = *reinterpret_cast<const et8*>(Ab + row * 128 + ((ls ^ ((row >> 1) & 7)) << 4));
                     }
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const int row = (wn * TN + j) * 32 + fr;
-                        bf[fb][j] = *reinterpret_cast<const bf16x8*>(Bb + row * 128 + ((ls ^ ((row >> 1) & 7)) << 4));
+                        bf[fb][j] = *reinterpret_cast<const et8*>(Bb + row * 128 + ((ls ^ ((row >> 1) & 7)) << 4));
                     }
                 };
                 load_frags(0, 0);
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cc & 1][i], bf[cc & 1][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma16(af[cc & 1][i], bf[cc & 1][j], acc[i][j]);
                 }
                 if (sb + 1 < s_end) store_step(buf ^ 1);
                 __syncthreads();
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
 }
 
 
-template <int WM, int WN, int TM, int TN, int KS>
+template <typename ET, int WM, int WN, int TM, int TN, int KS>
 static int launch_bf16(const ConvParams& p, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
@@ -325,22 +330,26 @@ static int launch_bf16(const ConvParams& p, hipStream_t s) {
     const size_t lds = lds_stage > lds_c ? lds_stage : lds_c;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16<WM, WN, TM, TN, KS>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16<ET, WM, WN, TM, TN, KS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     const int grid_x = (p.m_count && tiles > 1024) ? 1024 : tiles;
-    hipLaunchKernelGGL((conv_igemm_bf16<WM, WN, TM, TN, KS>), dim3(grid_x, p.splitk), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_igemm_bf16<ET, WM, WN, TM, TN, KS>), dim3(grid_x, p.splitk), dim3(256), lds, s, p);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 
-// The caller (apse_launch_conv) adds the split-K reduce pass.
-int apse_launch_conv_bf16(const ConvParams& p, int cfg, hipStream_t s) {
+// The caller (apse_launch_conv) adds the split-K reduce pass.  prec 1 = bf16, 2 = f16 operands.
+template <typename ET>
+static int launch_et(const ConvParams& p, int cfg, hipStream_t s) {
     switch (cfg) {
-        case 0: return launch_bf16<2, 2, 2, 2, 1>(p, s);
-        case 1: return launch_bf16<2, 2, 1, 1, 2>(p, s);
-        case 2: return launch_bf16<4, 1, 1, 1, 2>(p, s);
-        case 3: return launch_bf16<4, 1, 1, 2, 1>(p, s);
+        case 0: return launch_bf16<ET, 2, 2, 2, 2, 1>(p, s);
+        case 1: return launch_bf16<ET, 2, 2, 1, 1, 2>(p, s);
+        case 2: return launch_bf16<ET, 4, 1, 1, 1, 2>(p, s);
+        case 3: return launch_bf16<ET, 4, 1, 1, 2, 1>(p, s);
         default: return APSE_E_INVALID;
     }
+}
+int apse_launch_conv_bf16(const ConvParams& p, int cfg, hipStream_t s) {
+    return p.prec == 2 ? launch_et<_Float16>(p, cfg, s) : launch_et<__bf16>(p, cfg, s);
 }

@@ -242,13 +242,18 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     pack_oihw(rows.data(), Cout, Cin, KH, KW, cin_p, nullptr, packed.data(), KWCp);
     std::vector<float> bias_p(Cout_p, 0.f);
     for (size_t i = 0; i < bias.size(); ++i) bias_p[i] = bias[i];
-    const bool use_bf16 = (c->cfg.compute_dtype == 1 && Cout > 32 && sp.name != "assoc_fc");
+    const bool use_bf16 = (c->cfg.compute_dtype >= 1 && Cout > 32 && sp.name != "assoc_fc");      // bf16 or f16 operands
     float* wd = nullptr;
     uint16_t* wd16 = nullptr;
     if (use_bf16) {
-        // filters pre-rounded to bf16 (round-to-nearest-even, the rounding v_cvt_pk_bf16_f32 applies)
+        // filters pre-rounded to the 16-bit operand type (round-to-nearest-even, as the in-kernel converts do)
         std::vector<uint16_t> p16(packed.size());
         for (size_t i = 0; i < packed.size(); ++i) {
+            if (c->cfg.compute_dtype == 2) {
+                const _Float16 hval = (_Float16)packed[i];
+                memcpy(&p16[i], &hval, 2);
+                continue;
+            }
             uint32_t b;
             memcpy(&b, &packed[i], 4);
             if ((b & 0x7fffffffu) > 0x7f800000u) p16[i] = (uint16_t)((b >> 16) | 0x40);       // NaN stays NaN
@@ -279,7 +284,7 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     p.splitk = 1;
     p.out_mode = sp.deconv ? 1 : 0;
     // bf16 matrix cores for the bulk GEMMs; decision layers (narrow heads) and the association FC stay exact f32
-    p.prec = use_bf16 ? 1 : 0;
+    p.prec = use_bf16 ? c->cfg.compute_dtype : 0;
     p.cdec = sp.deconv ? Cout / 4 : 0;
     const int out_c = sp.deconv ? Cout / 4 : (y_ld_override > 0 ? y_ld_override : Cout);
     const int oh = sp.deconv ? 2 * p.OH : p.OH, ow = sp.deconv ? 2 * p.OW : p.OW;
@@ -995,7 +1000,7 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
     p.Cout = d->Cout; p.relu = d->relu; p.res_mode = d->res_mode;
     p.M = p.B * p.OH * p.OW; p.m_per_item = p.OH * p.OW;
     p.y_ld = d->Cout; p.steps_total = p.KH * (p.KWCp / 32);
-    p.prec = d->prec ? 1 : 0;
+    p.prec = (d->prec == 1 || d->prec == 2) ? d->prec : 0;
     int sk = 1;
     int cfg = apse_conv_pick_cfg(p.M, p.Cout, p.steps_total, &sk);
     if (d->cfg >= 0) { cfg = d->cfg; sk = 1; }

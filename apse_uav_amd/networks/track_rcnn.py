@@ -170,7 +170,7 @@ class TrackRCNN:
         ph = (c.image_h + 31) // 32 * 32
         pw = (c.image_w + 31) // 32 * 32
         c.assoc_scale = (pw // 4) / float(c.frame_w)          # features.size()[3] / image_size[1]  (rcnn_tracker.py:165)
-        c.compute_dtype = {"f32": 0, "bf16": 1}[str(cfg.APSE.DTYPE)]
+        c.compute_dtype = {"f32": 0, "bf16": 1, "f16": 2, "fp16": 2}[str(cfg.APSE.DTYPE)]
         ctx = C.c_void_p()
         _lib.check(lib.apse_create(C.byref(c), C.byref(ctx)), None, "apse_create: " + lib.apse_last_error(None).decode())
         try:

@@ -53,7 +53,7 @@ def main():
                     help="frames in flight per GPU: >1 runs consecutive steps on separate HIP streams / contexts so the "
                          "small-grid layers of one frame overlap with the next frame's (detection is stateless per "
                          "frame; the host association still consumes frames in order)")
-    ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16", "f16"],
                     help="f32 = exact-f32 MFMA (reference numerics, BASELINE configs[1]); bf16 = bf16 matrix cores with "
                          "f32 accumulate/storage for the bulk GEMMs (configs[2]/[4] style)")
     ap.add_argument("--bg-bias", type=float, default=None)

@@ -52,8 +52,8 @@ typedef struct apse_config {
     int assoc_roi;                /* 10 */
     int embed_dim;                /* 128 */
     float assoc_scale;            /* roi_pool spatial scale = p2 width / frame width (rcnn_tracker.py:165) */
-    int compute_dtype;            /* 0 = exact f32 MFMA everywhere (reference numerics); 1 = bf16 matrix cores with f32
-                                     accumulate and f32 storage for the trunk / head GEMMs (decision layers stay f32) */
+    int compute_dtype;            /* 0 = exact f32 MFMA everywhere (reference numerics); 1 = bf16, 2 = f16 matrix cores with
+                                     f32 accumulate and f32 storage for the trunk / head GEMMs (decision layers stay f32) */
 } apse_config;
 
 /* Byte offsets of the per-forward results block (one D2H copy, apse_read_results). n = max_batch*dets_per_image. */
@@ -149,7 +149,7 @@ typedef struct apse_conv_desc {
     int res_mode;           /* 0 none, 1 same-shape residual, 2 nearest-2x upsampled residual */
     int cfg;                /* -1 auto, else tile config 0..3 */
     int splitk;             /* 0 auto */
-    int prec;               /* 0 f32 MFMA, 1 bf16 MFMA (operands rounded at LDS staging, f32 accumulate) */
+    int prec;               /* 0 f32 MFMA; 1 bf16 / 2 f16 MFMA (operands rounded at LDS staging, f32 accumulate) */
     int fuse_reduce;        /* split-K: 1 = last-arriving block reduces in the launch, 0 = separate reduce kernel */
 } apse_conv_desc;
 size_t apse_conv_packed_elems(const apse_conv_desc* d);

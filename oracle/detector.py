@@ -40,8 +40,11 @@ F32_LAYERS = ("proposal_generator.rpn_head.objectness_logits", "proposal_generat
               "roi_heads.mask_head.predictor")
 
 
+_R16_DTYPE = [torch.bfloat16]
+
+
 def _r16(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(_R16_DTYPE[0]).to(torch.float32)
 
 
 def resize_shape(h, w, min_size=800, max_size=1333):
@@ -65,6 +68,10 @@ class DetectorOracle:
         if cfg:
             self.cfg.update(cfg)
         self.sd = {k: v.detach().to(torch.float32).cpu() for k, v in state_dict.items()}
+        if self.cfg["bf16"] == "f16":            # same emulation with IEEE half operands (BASELINE config 5)
+            _R16_DTYPE[0] = torch.float16
+        elif self.cfg["bf16"]:
+            _R16_DTYPE[0] = torch.bfloat16
 
     # ------------------------------------------------------------------ helpers
     def _conv(self, x, name, stride=1, padding=0, relu=False):

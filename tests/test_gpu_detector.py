@@ -142,7 +142,8 @@ def test_sequence_ids_and_csv(setup, logdir, tmp_path):
     assert same >= len(lines) - 1              # integer cells; a threshold-edge pixel may move one centroid by 1
 
 
-def test_bf16_mode_vs_bf16_oracle(setup, logdir):
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_bf16_mode_vs_bf16_oracle(setup, logdir, dtype):
     """cfg.APSE.DTYPE = "bf16": bf16 matrix cores, f32 accumulate / storage.  Checked against the oracle run
     with the same quantisation points (filters and layer inputs rounded to bf16).  A different f32
     accumulation order can flip the bf16 rounding of a next-layer input (2^-9 relative), so the float
@@ -151,22 +152,23 @@ def test_bf16_mode_vs_bf16_oracle(setup, logdir):
     from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
     from oracle.detector import DetectorOracle
     cfg = _cfg()
-    cfg.APSE.DTYPE = "bf16"
+    cfg.APSE.DTYPE = dtype
     tr = RcnnTracker(cfg, FRAME, setup["asd"], detector_state=setup["sd"])
     frame = setup["seq"].frame(0)
     pred, feats = tr.predictor(frame)
     inst = pred["instances"]
-    oracle = DetectorOracle(setup["sd"], dict(depth_blocks=BLOCKS, min_size=256, max_size=448, bf16=True))
+    oracle = DetectorOracle(setup["sd"], dict(depth_blocks=BLOCKS, min_size=256, max_size=448,
+                                              bf16=("f16" if dtype == "f16" else True)))
     img = np.asarray(Image.fromarray(frame).resize((setup["iw"], setup["ih"]), Image.BILINEAR))
     post = oracle.inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), FRAME[0], FRAME[1])
     for k in ("p2", "p4", "p6"):
         got, ref = feats[k].cpu(), post["features"][k]
         d = float((got - ref).abs().max() / ref.abs().max())
         mean = float((got - ref).abs().mean() / ref.abs().mean())
-        _log(logdir, "bf16/feat/" + k, dict(rel_max=d, rel_mean=mean))
+        _log(logdir, dtype + "/feat/" + k, dict(rel_max=d, rel_mean=mean))
         assert d < 3e-2 and mean < 1e-2        # bf16 noise floor: ~2^-9 after the roundings decorrelate
     n, rn = len(inst), int(post["boxes"].shape[0])
-    _log(logdir, "bf16/dets", dict(n=n, ref_n=rn, scores=[round(float(s), 4) for s in inst.scores],
+    _log(logdir, dtype + "/dets", dict(n=n, ref_n=rn, scores=[round(float(s), 4) for s in inst.scores],
                                    ref=[round(float(s), 4) for s in post["scores"]]))
     assert abs(n - rn) <= 2
     matched = 0
@@ -175,7 +177,7 @@ def test_bf16_mode_vs_bf16_oracle(setup, logdir):
         d = (post["boxes"] - b).abs().max(dim=1).values if rn else torch.tensor([])
         if rn and float(d.min()) < 2.0:
             matched += 1
-    _log(logdir, "bf16/matched", dict(matched=matched, n=n))
+    _log(logdir, dtype + "/matched", dict(matched=matched, n=n))
     assert matched >= min(n, rn) - 2
 
 

@@ -65,8 +65,9 @@ def test_conv2d_parity(case, logdir):
     assert st["rel_to_max"] < 2e-5, st          # f32 tolerance: accumulation-order noise only
 
 
+@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "f16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv2d_bf16_parity(case, logdir):
+def test_conv2d_bf16_parity(case, prec, logdir):
     """bf16 matrix-core variant: operands rounded to bf16 at staging, f32 accumulate/storage.  Reference =
     torch CPU f32 convolution of the bf16-rounded operands (same quantisation points)."""
     from hip_helpers import hip_conv2d, err_stats
@@ -76,7 +77,7 @@ def test_conv2d_bf16_parity(case, logdir):
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
     b = torch.randn(Cout, generator=g)
-    r16 = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    r16 = lambda t: t.to(torch.bfloat16 if prec == 1 else torch.float16).to(torch.float32)
     ref = F.conv2d(r16(x), r16(w), b, stride=stride, padding=pad)
     res = None
     if res_mode == 1:
@@ -87,9 +88,9 @@ def test_conv2d_bf16_parity(case, logdir):
         ref = ref + F.interpolate(res, scale_factor=2, mode="nearest")
     if relu:
         ref = F.relu(ref)
-    out = hip_conv2d(x, w, b, stride, pad, relu, res, res_mode, cfg, splitk, prec=1)
+    out = hip_conv2d(x, w, b, stride, pad, relu, res, res_mode, cfg, splitk, prec=prec)
     st = err_stats(out, ref)
-    _log(logdir, "conv_bf16/" + name, st)
+    _log(logdir, "conv_16bit/%d/" % prec + name, st)
     assert st["nan"] == 0
     assert st["rel_to_max"] < 2e-5, st          # products of bf16 values are exact in f32: order-of-sum noise only
 
