@@ -44,7 +44,9 @@ struct ConvParams {
     int prec;             // 0: exact f32 MFMA; 1: operands rounded to bf16 at LDS staging, f32 accumulate (f32 storage)
 };
 
-int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s);   // cfg: 0=128x128 1=64x64 2=128x32 3=128x64
+// cfg: 0=128x128 1=64x64 2=128x32 3=128x64.  ev0/ev1 (optional) are recorded right before / after the
+// implicit-GEMM kernel itself (a split-K reduce pass, if any, follows ev1).
+int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk);
 int apse_launch_conv_bf16(const ConvParams& p, int cfg, hipStream_t s);   // conv_igemm_bf16.hip
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvParams p) {
 }
 
 template <int WM, int WN, int TM, int TN, int KS>
-static int launch_cfg(const ConvParams& p, hipStream_t s) {
+static int launch_cfg(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
     const size_t lds_stage = (size_t)2 * KS * (BM + BN) * 32 * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float) + 16;
@@ -359,7 +359,9 @@ static int launch_cfg(const ConvParams& p, hipStream_t s) {
         attr_done = true;
     }
     const int grid_x = (p.m_count && tiles > 1024) ? 1024 : tiles;
+    if (ev0) hipEventRecord(ev0, s);
     hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, KS>), dim3(grid_x, p.splitk), dim3(256), lds, s, p);
+    if (ev1) hipEventRecord(ev1, s);
     if (p.splitk > 1 && !p.tile_cnt) {
         const size_t total = (size_t)p.M * p.Cout;
         int blocks = (int)((total + 255) / 256);
@@ -369,11 +371,13 @@ static int launch_cfg(const ConvParams& p, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 
-int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s) {
+int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (p.M <= 0 || p.Cout <= 0 || p.steps_total <= 0) return APSE_E_INVALID;
     if (p.res_mode != 0 && (p.Cout & 3) != 0) return APSE_E_INVALID;      // residual rows are read as float4
     if (p.prec == 1 || p.prec == 2) {
+        if (ev0) hipEventRecord(ev0, s);
         int rc = apse_launch_conv_bf16(p, cfg, s);
+        if (ev1) hipEventRecord(ev1, s);
         if (rc == APSE_OK && p.splitk > 1 && !p.tile_cnt) {
             const size_t total = (size_t)p.M * p.Cout;
             int blocks = (int)((total + 255) / 256);
@@ -383,10 +387,10 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s) {
         return rc;
     }
     switch (cfg) {
-        case 0: return launch_cfg<2, 2, 2, 2, 1>(p, s);
-        case 1: return launch_cfg<2, 2, 1, 1, 2>(p, s);
-        case 2: return launch_cfg<4, 1, 1, 1, 2>(p, s);
-        case 3: return launch_cfg<4, 1, 1, 2, 1>(p, s);
+        case 0: return launch_cfg<2, 2, 2, 2, 1>(p, s, ev0, ev1);
+        case 1: return launch_cfg<2, 2, 1, 1, 2>(p, s, ev0, ev1);
+        case 2: return launch_cfg<4, 1, 1, 1, 2>(p, s, ev0, ev1);
+        case 3: return launch_cfg<4, 1, 1, 2, 1>(p, s, ev0, ev1);
         default: return APSE_E_INVALID;
     }
 }

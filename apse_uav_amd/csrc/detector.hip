@@ -337,15 +337,16 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
             }
             else if (st.c.count_kind == 1 && batch == 1) p.m_count = propcnt_dev;
             int e0 = -1;
-            if (c->prof_on && c->ev_used + 2 <= (int)c->ev_pool.size()) {
-                e0 = c->ev_used; c->ev_used += 2;
-                hipEventRecord(c->ev_pool[e0], s);
+            if (c->prof_on && c->ev_used == 0) {
+                // calibration pair: two back-to-back records; their elapsed time (the marker overhead a timed
+                // kernel also pays) is subtracted from every measurement of this forward
+                hipEventRecord(c->ev_pool[0], s);
+                hipEventRecord(c->ev_pool[1], s);
+                c->ev_used = 2;
             }
-            rc = apse_launch_conv(p, cfg, s);
-            if (e0 >= 0) {
-                hipEventRecord(c->ev_pool[e0 + 1], s);
-                c->pending.push_back({cfg, st.c.flops_per_item, st.c.count_kind, st.c.b_mult, batch, e0, e0 + 1});
-            }
+            if (c->prof_on && c->ev_used + 2 <= (int)c->ev_pool.size()) { e0 = c->ev_used; c->ev_used += 2; }
+            rc = apse_launch_conv(p, cfg, s, e0 >= 0 ? c->ev_pool[e0] : nullptr, e0 >= 0 ? c->ev_pool[e0 + 1] : nullptr);
+            if (e0 >= 0) c->pending.push_back({cfg, st.c.flops_per_item, st.c.count_kind, st.c.b_mult, batch, e0, e0 + 1});
         } else if (st.kind == S_MAXPOOL) {
             rc = apse_k_maxpool3x3s2(st.x, st.y, batch, st.H, st.W, st.C, s);
         } else {
@@ -860,9 +861,12 @@ int apse_read_results(apse_ctx* c, void* host_dst, size_t bytes, void* stream) {
         const uint8_t* h = reinterpret_cast<const uint8_t*>(host_dst);
         const int total = *reinterpret_cast<const int*>(h + c->lay.total);
         const int* pc = reinterpret_cast<const int*>(h + c->lay.prop_count);
+        float cal = 0.f;
+        if (c->ev_used >= 2 && hipEventElapsedTime(&cal, c->ev_pool[0], c->ev_pool[1]) != hipSuccess) cal = 0.f;
         for (auto& q : c->pending) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, c->ev_pool[q.e0], c->ev_pool[q.e1]) != hipSuccess) continue;
+            ms = ms > cal ? ms - cal : ms;
             double items = q.batch;
             if (q.count_kind == 1) { items = 0; for (int b = 0; b < q.batch; ++b) items += pc[b]; }
             else if (q.count_kind == 2) items = total;

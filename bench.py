@@ -49,6 +49,9 @@ def main():
                     help="frames start in pinned host memory and are uploaded inside the timed region on a copy stream "
                          "(double-buffered, overlapped with compute): the PCIe-inclusive rate noted in DESIGN.md, never "
                          "the headline value")
+    ap.add_argument("--throughput-depth", type=int, default=3,
+                    help="after the timed region, also measure a pipelined run with this many frames in flight and "
+                         "report it as `throughput_mode` (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="frames in flight per GPU: >1 runs consecutive steps on separate HIP streams / contexts so the "
                          "small-grid layers of one frame overlap with the next frame's (detection is stateless per "
@@ -243,11 +246,68 @@ def main():
                          "conv_ms_per_frame": round(total_conv_ms / max(n_instr * B, 1), 3), "instrumented_steps": n_instr,
                          "whole_path_tflops": round(flops_frame * fps / world / 1e12, 3)},
         }
+        if world == 1 and depth == 1 and args.throughput_depth > 1 and not args.from_host:
+            out["throughput_mode"] = throughput_mode(cfg, sd, tracker, model, frames, nres, B, args.throughput_depth)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, asd, host_frames, blocks, H, W, args.cpu_frames, args.cpu_threads)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def throughput_mode(cfg, sd, tracker, model, frames, nres, B, depth, steps=24, warmup=4):
+    """Same frames, same per-frame results, `depth` frames in flight on separate streams / contexts: the
+    small-grid layers of one frame (res4/res5 at batch 1 fill ~1 block per CU) overlap with other frames'.
+    Informational: the headline value is the single-stream run above."""
+    from apse_uav_amd.networks.track_rcnn import TrackRCNN
+    models = [model]
+    for _ in range(depth - 1):
+        m2 = TrackRCNN(cfg)
+        m2.load_state_dict(sd)
+        m2.attach_association_head(tracker.association_head)
+        models.append(m2)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(depth - 1)]
+
+    def submit(i):
+        k = i % depth
+        idx = [(i * B + j) % nres for j in range(B)]
+        batch = frames[idx] if B > 1 else frames[idx[0]:idx[0] + 1]
+        with torch.cuda.stream(streams[k]):
+            models[k].preprocess_frames(batch)
+            models[k].run(B)
+
+    def collect(i):
+        k = i % depth
+        with torch.cuda.stream(streams[k]):
+            res = models[k].read(B)
+        for b in range(B):
+            objs = tracker.next_record(res.record(b))
+            tracker.log_line(objs, 1, i * B + b)
+
+    lat = []
+    t0 = None
+    inflight = []
+    for i in range(warmup + steps):
+        if i == warmup:
+            while inflight:
+                collect(inflight.pop(0)[0])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        inflight.append((i, time.perf_counter()))
+        submit(i)
+        if len(inflight) == depth:
+            j, ts = inflight.pop(0)
+            collect(j)
+            if i >= warmup:
+                lat.append(time.perf_counter() - ts)
+    while inflight:
+        j, ts = inflight.pop(0)
+        collect(j)
+        lat.append(time.perf_counter() - ts)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"frames_in_flight": depth, "value": round(steps * B / dt, 3), "unit": "frames/s",
+            "p50_ms_per_frame": round(1000.0 * float(np.median(lat)) / B, 3), "steps": steps}
 
 
 def cpu_baseline(sd, asd, host_frames, blocks, H, W, nframes, max_threads):
