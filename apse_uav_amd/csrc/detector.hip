@@ -31,9 +31,9 @@ int apse_k_subsample2(const float*, float*, int, int, int, int, hipStream_t);
 int apse_k_nhwc_to_nchw(const float*, float*, int, int, int, hipStream_t);
 int apse_k_rpn_topk_stage(const RpnLevels*, const TopkJob*, int, uint64_t*, int, int, uint32_t*, hipStream_t);
 int apse_k_rpn_decode(const RpnLevels*, int, const uint64_t*, int, const int*, float, float, float, float*, float*, int*,
-                      uint32_t*, int, hipStream_t);
+                      uint32_t*, int, int, hipStream_t);
 int apse_k_nms_percat(const float*, const float*, const int*, int, int, int, const uint32_t*, float, int*, int*, int,
-                      void*, int, hipStream_t);
+                      void*, int, int, hipStream_t);
 size_t apse_nms_scratch_bytes(int slots);
 int apse_k_rank_final(const float*, const float*, int, const int*, const int*, int, int, float*, float*, int*, int*, uint32_t*,
                       int, hipStream_t);
@@ -703,8 +703,12 @@ int apse_backbone(apse_ctx* c, int batch, void* stream) {
     return run_plan(c, c->backbone, batch, (hipStream_t)stream);
 }
 
-int apse_rpn(apse_ctx* c, int batch, void* stream) {
+int apse_rpn_levels(apse_ctx* c, int batch, int level_mask, void* stream) {
     NEED_READY(c, batch);
+    level_mask &= 31;
+    if (!level_mask) return fail(c, APSE_E_INVALID, "empty RPN level mask");
+    int first_level = 0;
+    while (!((level_mask >> first_level) & 1)) ++first_level;
     hipStream_t s = (hipStream_t)stream;
     const apse_config& g = c->cfg;
     int rc = run_plan(c, c->rpnhead, batch, s);
@@ -715,10 +719,10 @@ int apse_rpn(apse_ctx* c, int batch, void* stream) {
         if (rc) return fail(c, rc, "rpn top-k stage launch failed");
     }
     rc = apse_k_rpn_decode(c->rl_dev, g.rpn_pre_topk, c->lists, c->nslots, c->final_slot_dev, (float)g.image_h, (float)g.image_w,
-                           (float)log(1000.0 / 16.0), c->dec_boxes, c->dec_scores, c->dec_valid, c->maxc, batch, s);
+                           (float)log(1000.0 / 16.0), c->dec_boxes, c->dec_scores, c->dec_valid, c->maxc, level_mask, batch, s);
     if (rc) return fail(c, rc, "rpn decode launch failed");
     rc = apse_k_nms_percat(c->dec_boxes, c->dec_scores, c->dec_valid, 5 * g.rpn_pre_topk, g.rpn_pre_topk, 0, c->maxc, g.rpn_nms,
-                           c->keep_idx, c->keep_cnt, 5, c->nms_scratch, batch, s);
+                           c->keep_idx, c->keep_cnt, 5, c->nms_scratch, first_level, batch, s);
     if (rc) return fail(c, rc, "rpn nms launch failed");
     int* propcnt = reinterpret_cast<int*>(c->res + c->lay.prop_count);
     rc = apse_k_rank_final(c->dec_boxes, c->dec_scores, 5 * g.rpn_pre_topk, c->keep_idx, c->keep_cnt, 5, g.rpn_post_topk, c->props,
@@ -727,6 +731,8 @@ int apse_rpn(apse_ctx* c, int batch, void* stream) {
     if (rc) return fail(c, rc, "rpn rank launch failed");
     return APSE_OK;
 }
+
+int apse_rpn(apse_ctx* c, int batch, void* stream) { return apse_rpn_levels(c, batch, 31, stream); }
 
 static int pack_from_dets(apse_ctx* c, int batch, hipStream_t s) {
     const apse_config& g = c->cfg;
@@ -755,7 +761,7 @@ int apse_box_head(apse_ctx* c, int batch, void* stream) {
                                c->maxc + g.max_batch, c->probs, batch, s);
     if (rc) return fail(c, rc, "box candidates launch failed");
     rc = apse_k_nms_percat(c->cand_boxes, c->cand_scores, c->cand_valid, P * K, 0, K, c->maxc + g.max_batch, g.box_nms, c->keep_idx,
-                           c->keep_cnt, K, c->nms_scratch, batch, s);
+                           c->keep_cnt, K, c->nms_scratch, 0, batch, s);
     if (rc) return fail(c, rc, "box nms launch failed");
     rc = apse_k_rank_final(c->cand_boxes, c->cand_scores, P * K, c->keep_idx, c->keep_cnt, K, g.dets_per_image, c->det_boxes,
                            c->det_scores, c->det_entry, c->det_cnt, nullptr, batch, s);
@@ -1078,7 +1084,7 @@ int apse_nms_rank(const float* boxes, const float* scores, const int* valid, int
     hipMemcpy(maxc, &mb, 4, hipMemcpyHostToDevice);
     void* scratch = nullptr;
     if (hipMalloc(&scratch, apse_nms_scratch_bytes(8)) != hipSuccess) return APSE_E_NOMEM;
-    int rc = apse_k_nms_percat(boxes, scores, valid, n, cat_div, cat_mod, maxc, thr, keep_idx, keep_cnt, ncat, scratch, 1, s);
+    int rc = apse_k_nms_percat(boxes, scores, valid, n, cat_div, cat_mod, maxc, thr, keep_idx, keep_cnt, ncat, scratch, 0, 1, s);
     if (!rc) rc = apse_k_rank_final(boxes, scores, n, keep_idx, keep_cnt, ncat, topk, out_boxes, out_scores, out_index, out_count, nullptr, 1, s);
     hipStreamSynchronize(s);
     hipFree(keep_idx); hipFree(keep_cnt); hipFree(maxc); hipFree(scratch);

@@ -137,14 +137,14 @@ __global__ __launch_bounds__(1024) void rpn_topk_stage(const RpnLevels* __restri
 __global__ __launch_bounds__(256) void rpn_decode(const RpnLevels* __restrict__ Lp, const uint64_t* __restrict__ lists, int nslots,
                                                   const int* __restrict__ final_slot, float img_h, float img_w,
                                                   float scale_clamp, float* __restrict__ boxes, float* __restrict__ scores,
-                                                  int* __restrict__ valid, uint32_t* __restrict__ maxc) {
+                                                  int* __restrict__ valid, uint32_t* __restrict__ maxc, int level_mask) {
     const int b = blockIdx.z, l = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int pre_topk = Lp->pre_topk, head_ld = Lp->head_ld;
     if (i >= pre_topk) return;
     const RpnLevel lv = Lp->lv[l];
     const size_t o = (size_t)b * 5 * pre_topk + (size_t)l * pre_topk + i;
-    if (i >= lv.k) { valid[o] = 0; scores[o] = 0.f; return; }
+    if (i >= lv.k || !((level_mask >> l) & 1)) { valid[o] = 0; scores[o] = 0.f; return; }
     const uint64_t key = lists[((size_t)b * nslots + final_slot[l]) * 1024 + i];
     const uint32_t e = (uint32_t)key;
     const float sc = comp_score(key);
@@ -191,7 +191,7 @@ struct NmsScratch {
 
 __global__ __launch_bounds__(1024) void nms_prepare(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                     const int* __restrict__ valid, int n_total, int cat_div, int cat_mod,
-                                                    const uint32_t* __restrict__ maxc, NmsScratch S, int ncat) {
+                                                    const uint32_t* __restrict__ maxc, NmsScratch S, int ncat, int cat_shift) {
     __shared__ uint64_t keys[NMS_MAX];
     __shared__ int wsum[17];
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -223,7 +223,8 @@ __global__ __launch_bounds__(1024) void nms_prepare(const float* __restrict__ bo
     int n = wsum[16];
     n = n < NMS_MAX ? n : NMS_MAX;
     bitonic_sort_lds<NMS_MAX, 1024>(keys, tid);
-    const float off = (float)c * (__uint_as_float(maxc[b]) + 1.0f);
+    // batched_nms numbers the categories that are present in the call: cat_shift = index of the first one
+    const float off = (float)(c - cat_shift) * (__uint_as_float(maxc[b]) + 1.0f);
     float* bx = S.box + slot * 4 * NMS_MAX;
     if (tid < n) {
         const uint32_t e = (uint32_t)keys[tid];
@@ -468,9 +469,9 @@ int apse_k_rpn_topk_stage(const RpnLevels* L_dev, const TopkJob* jobs_dev, int n
 }
 int apse_k_rpn_decode(const RpnLevels* L_dev, int pre_topk, const uint64_t* lists, int nslots, const int* final_slot_dev,
                       float img_h, float img_w, float scale_clamp, float* boxes, float* scores, int* valid, uint32_t* maxc,
-                      int B, hipStream_t s) {
+                      int level_mask, int B, hipStream_t s) {
     hipLaunchKernelGGL(rpn_decode, dim3((pre_topk + 255) / 256, 5, B), dim3(256), 0, s, L_dev, lists, nslots, final_slot_dev,
-                       img_h, img_w, scale_clamp, boxes, scores, valid, maxc);
+                       img_h, img_w, scale_clamp, boxes, scores, valid, maxc, level_mask);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 size_t apse_nms_scratch_bytes(int slots) {
@@ -487,8 +488,8 @@ static NmsScratch carve(void* scratch, int slots) {
     return S;
 }
 int apse_k_nms_percat(const float* boxes, const float* scores, const int* valid, int n_total, int cat_div, int cat_mod,
-                      const uint32_t* maxc, float thr, int* keep_idx, int* keep_cnt, int ncat, void* scratch, int B,
-                      hipStream_t s) {
+                      const uint32_t* maxc, float thr, int* keep_idx, int* keep_cnt, int ncat, void* scratch, int cat_shift,
+                      int B, hipStream_t s) {
     static bool done = false;
     if (!done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -497,7 +498,7 @@ int apse_k_nms_percat(const float* boxes, const float* scores, const int* valid,
     }
     NmsScratch S = carve(scratch, ncat * B);
     hipLaunchKernelGGL(nms_prepare, dim3(ncat, B), dim3(1024), 0, s, boxes, scores, valid, n_total, cat_div, cat_mod, maxc, S,
-                       ncat);
+                       ncat, cat_shift);
     hipLaunchKernelGGL(nms_matrix, dim3(16, 16, ncat * B), dim3(64), 0, s, S, thr);
     hipLaunchKernelGGL(nms_scan, dim3(ncat, B), dim3(1024), NMS_MAX * 16 * 8, s, S, keep_idx, keep_cnt);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;

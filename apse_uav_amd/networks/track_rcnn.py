@@ -221,11 +221,11 @@ class TrackRCNN:
         self._call("apse_preprocess_images", _lib.ptr(images.contiguous()), B, _lib.stream_ptr())
         return B
 
-    def run(self, batch, given=None):
+    def run(self, batch, given=None, rpn_levels=31):
         s = _lib.stream_ptr()
         self._call("apse_backbone", batch, s)
         if given is None:
-            self._call("apse_rpn", batch, s)
+            self._call("apse_rpn_levels", batch, int(rpn_levels), s)
             self._call("apse_box_head", batch, s)
         else:
             boxes, classes, counts = given
@@ -306,9 +306,9 @@ class TrackRCNN:
         out = [{"instances": self.instances_from(res, b)} for b in range(B)]
         return out, LazyFeatures(self, B)
 
-    def inference_frames(self, frames, given=None, want_masks=True):
+    def inference_frames(self, frames, given=None, want_masks=True, rpn_levels=31):
         """Fused path: uint8 CUDA frames [B, H, W, 3] -> (list of Instances, feature dict)."""
         B = self.preprocess_frames(frames)
-        self.run(B, given)
+        self.run(B, given, rpn_levels)
         res = self.read(B)
         return [self.instances_from(res, b, want_masks) for b in range(B)], LazyFeatures(self, B)

@@ -106,6 +106,9 @@ int apse_preprocess_images(apse_ctx* ctx, const float* images_dev, int batch, vo
 int apse_backbone(apse_ctx* ctx, int batch, void* stream);
 /* RPN head + proposal selection (track_rcnn.py:46). */
 int apse_rpn(apse_ctx* ctx, int batch, void* stream);
+/* Same with proposals taken only from the FPN levels in `level_mask` (bit 0 = p2 .. bit 4 = p6); mask 16 is
+ * SelectiveRPN.gen_partial_proposals (dcnn/networks/selective_rpn.py:14-86: last level only). */
+int apse_rpn_levels(apse_ctx* ctx, int batch, int level_mask, void* stream);
 /* Box branch + FastRCNNOutputs.inference (track_rcnn.py:51) -> packed detection list. */
 int apse_box_head(apse_ctx* ctx, int batch, void* stream);
 /* roi_heads.forward_with_given_boxes (track_rcnn.py:52-54): host arrays, boxes in resized-image pixels,

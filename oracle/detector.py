@@ -163,7 +163,7 @@ class DetectorOracle:
             deltas.append(self._conv(t, "proposal_generator.rpn_head.anchor_deltas"))
         return logits, deltas
 
-    def rpn_select(self, logits, deltas, image_size):
+    def rpn_select(self, logits, deltas, image_size, levels=None):
         """detectron2 RPNOutputs.predict_* + find_top_rpn_proposals (batch 1).
 
         Returns dict(boxes [P,4], logits [P], plus per-stage intermediates)."""
@@ -171,6 +171,8 @@ class DetectorOracle:
         h_img, w_img = image_size
         top_scores, top_boxes, top_idx, lvls = [], [], [], []
         for li, (lg, dl) in enumerate(zip(logits, deltas)):
+            if levels is not None and li not in levels:
+                continue                       # SelectiveRPN: only some levels reach find_top_rpn_proposals
             _, A, H, W = lg.shape
             lg_f = lg.permute(0, 2, 3, 1).reshape(-1)                       # (y, x, a)
             dl_f = dl.view(1, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(-1, 4)
@@ -182,7 +184,7 @@ class DetectorOracle:
             top_scores.append(lg_f[order])
             top_boxes.append(props)
             top_idx.append(order)
-            lvls.append(torch.full((k,), li, dtype=torch.int64))
+            lvls.append(torch.full((k,), len(lvls), dtype=torch.int64))      # level ids count the levels present
         scores = torch.cat(top_scores)
         boxes = torch.cat(top_boxes)
         lvl = torch.cat(lvls)
@@ -264,7 +266,7 @@ class DetectorOracle:
         return dict(boxes=b, scores=scores, classes=classes, mask_windows=windows, mask_rects=rects, keep=keep)
 
     # ------------------------------------------------------------------ whole path
-    def inference(self, image_chw, out_h, out_w, given_boxes=None, given_classes=None):
+    def inference(self, image_chw, out_h, out_w, given_boxes=None, given_classes=None, rpn_levels=None):
         """TrackRCNN.inference on one image (track_rcnn.py:16-58).  image_chw is the
         *resized* f32 CHW BGR image; out_h/out_w the original frame size.  With
         ``given_boxes`` (resized-image coordinates) the box branch is skipped
@@ -274,7 +276,7 @@ class DetectorOracle:
         feats = self.backbone(x)
         if given_boxes is None:
             lg, dl = self.rpn_head(feats)
-            prop = self.rpn_select(lg, dl, image_size)
+            prop = self.rpn_select(lg, dl, image_size, rpn_levels)
             bf = self.box_features(feats, prop["boxes"])
             det = self.box_inference(bf["cls_logits"], bf["deltas"], prop["boxes"], image_size)
             boxes, scores, classes = det["boxes"], det["scores"], det["classes"]

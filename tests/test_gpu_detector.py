@@ -214,3 +214,25 @@ def test_no_detections_and_full_list(setup, logdir):
             assert hi == 100 and len(line.split(",")) == 1 + 4 * 100
             objs2 = tr.next_frame(frame)                       # same frame again: every object re-associated
             assert sorted(objs2.ids) == list(range(1, 101))
+
+
+def test_selective_predictor_last_level_only(setup, logdir):
+    """SelectivePredictor: proposals from p6 only, then the standard ROI heads."""
+    from PIL import Image
+    from apse_uav_amd.engines.selective_predictor import SelectivePredictor
+    from oracle.detector import DetectorOracle
+    frame = setup["seq"].frame(0)
+    pr = SelectivePredictor(_cfg(), state_dict=setup["sd"])
+    inst = pr(frame)["instances"]
+    P = int(pr.model.last_results.prop_count[0])
+    oracle = DetectorOracle(setup["sd"], dict(depth_blocks=BLOCKS, min_size=256, max_size=448))
+    img = np.asarray(Image.fromarray(frame).resize((setup["iw"], setup["ih"]), Image.BILINEAR))
+    post = oracle.inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), FRAME[0], FRAME[1], rpn_levels=[4])
+    ref_props = post["proposals"]["boxes"]
+    props = pr.model.debug_tensor("proposals").cpu().view(-1, 4)[:P]
+    _log(logdir, "selective", dict(P=P, ref_P=int(ref_props.shape[0]), n=len(inst), ref_n=int(post["boxes"].shape[0])))
+    assert P == ref_props.shape[0] and P <= 4 * 7 * 3
+    assert float((props - ref_props).abs().max()) < 1e-2
+    assert len(inst) == post["boxes"].shape[0]
+    if len(inst):
+        assert float((inst.pred_boxes.tensor - post["boxes"]).abs().max()) < 5e-2
