@@ -236,3 +236,36 @@ def test_selective_predictor_last_level_only(setup, logdir):
     assert len(inst) == post["boxes"].shape[0]
     if len(inst):
         assert float((inst.pred_boxes.tensor - post["boxes"]).abs().max()) < 5e-2
+
+
+def test_sharded_replay_equals_sequential(setup, logdir, tmp_path):
+    """BASELINE config 4 semantics on one GPU: detect two contiguous frame shards independently (as two
+    ranks would), concatenate their records (what the gather delivers) and replay the association: ids
+    and CSV lines must equal the frame-by-frame tracker run.  The collective itself is covered by the
+    2-rank gloo test."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_sequence as rs
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from apse_uav_amd.sharding import pack_record, shard_frames, unpack_record
+    from apse_uav_amd.utils import csv_log
+    n = 6
+    seq = setup["seq"]
+    seq_tr = RcnnTracker(_cfg(), FRAME, setup["asd"], detector_state=setup["sd"])
+    ref_lines = []
+    for t in range(n):
+        objs = seq_tr.next_frame(seq.frame(t))
+        ref_lines.append(seq_tr.log_line(objs, 1, t)[0])
+    recs = []
+    for rank in range(2):
+        lo, hi = shard_frames(n, rank, 2)
+        w = RcnnTracker(_cfg(), FRAME, setup["asd"], detector_state=setup["sd"])
+        part = rs.detect_range(w, seq.frame, lo, hi, 1)
+        recs += [unpack_record(pack_record(r, 100, 128), 100, 128) for r in part]      # through the wire format
+    rep = RcnnTracker(_cfg(), FRAME, setup["asd"], detector_state=setup["sd"])
+    lines, max_id = rs.replay(rep, recs, 1)
+    _log(logdir, "sharded", dict(equal=sum(a == b for a, b in zip(lines, ref_lines)), n=n))
+    assert lines == ref_lines
+    p = tmp_path / "a.csv"
+    csv_log.write_consumer_csv(str(p), lines, 1, [2, 3, 4])
+    assert len(csv_log.read_centroid_data(str(p))) == n
