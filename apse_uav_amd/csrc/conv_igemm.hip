@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     constexpr int AP = BM / 32;   // staging passes (32 rows x 8 slots of 16 B per pass)
     constexpr int BP = BN / 32;
     constexpr int LDC = BN + 4;
+    constexpr int STORE_AT = 4 * KS - 2;          // chunk before which the next k-slice is written to LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);   // [2][KS][BM*32]
     float* Bs = As + 2 * KS * BM * 32;            // [2][KS][BN*32]
@@ -175,6 +176,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
 #pragma unroll
                 for (int cc = 0; cc < 4 * KS; ++cc) {
                     if (cc + 1 < 4 * KS) load_frags(cc + 1, (cc + 1) & 1);
+                    // the next step's tile goes to LDS in the middle of this step's MFMA stream (its global
+                    // loads were issued at the top of the step): the ds_writes issue under the matrix pipe
+                    // instead of in front of the barrier.  buf^1 was last read in the previous step.
+                    if (cc == STORE_AT && sb + 1 < s_end) store_step(buf ^ 1);
+#ifdef APSE_SETPRIO
+                    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -182,8 +190,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cc & 1][i][k], bf[cc & 1][j][k], acc[i][j], 0, 0, 0);
+#ifdef APSE_SETPRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                 }
-                if (sb + 1 < s_end) store_step(buf ^ 1);
                 __syncthreads();
             }
         }

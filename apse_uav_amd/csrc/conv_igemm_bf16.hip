@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
     constexpr int AP = BM / 32;   // staging passes (32 rows x 8 slots of 16 B per pass)
     constexpr int BP = BN / 32;
     constexpr int LDC = BN + 4;
+    constexpr int STORE_AT = 4 * KS - 2;          // chunk before which the next k-slice is written to LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                              // [2][KS][BM][64 bf16]  (128-byte rows, 16-byte slots)
     char* Bs = As + 2 * KS * BM * 128;            // [2][KS][BN][64 bf16]
@@ -192,13 +193,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
 #pragma unroll
                 for (int cc = 0; cc < 4 * KS; ++cc) {
                     if (cc + 1 < 4 * KS) load_frags(cc + 1, (cc + 1) & 1);
+                    if (cc == STORE_AT && sb + 1 < s_end) store_step(buf ^ 1);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = mfma16(af[cc & 1][i], bf[cc & 1][j], acc[i][j]);
                 }
-                if (sb + 1 < s_end) store_step(buf ^ 1);
                 __syncthreads();
             }
         }

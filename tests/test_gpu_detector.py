@@ -269,3 +269,42 @@ def test_sharded_replay_equals_sequential(setup, logdir, tmp_path):
     p = tmp_path / "a.csv"
     csv_log.write_consumer_csv(str(p), lines, 1, [2, 3, 4])
     assert len(csv_log.read_centroid_data(str(p))) == n
+
+
+def test_config3_like_batch4_bf16_with_preproc(setup, logdir, golden_dir):
+    """BASELINE config 3 in miniature: dynamic sequence, batch 4, bf16 matrix cores, undistort + gamma HIP
+    pre-processing in front of the resize.  Checked against the oracle fed with oracle/preproc.py's frames and
+    run in bf16-emulation mode; detections are matched by position (16-bit noise floor)."""
+    from PIL import Image
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from oracle import preproc as op
+    from oracle.detector import DetectorOracle
+    with open(os.path.join(golden_dir, "cam_params.json")) as f:
+        cam = json.load(f)
+    s = FRAME[1] / 3840.0                                   # intrinsics of the 4K camera scaled to the test frame
+    mtx = np.asarray(cam["mtx"], np.float64)
+    mtx[0] *= s
+    mtx[1] *= s
+    cam_small = dict(mtx=mtx.tolist(), dist=cam["dist"])
+    cfg = _cfg()
+    cfg.APSE.DTYPE = "bf16"
+    cfg.APSE.MAX_BATCH = 4
+    tr = RcnnTracker(cfg, FRAME, setup["asd"], detector_state=setup["sd"])
+    tr.predictor.set_camera(cam_small)
+    frames = [setup["seq"].frame(t) for t in range(4)]
+    out = tr.predictor.predict_batch(frames, want_masks=False)[0]
+    oracle = DetectorOracle(setup["sd"], dict(depth_blocks=BLOCKS, min_size=256, max_size=448, bf16=True))
+    tot = matched = 0
+    for b in range(4):
+        pre = op.preprocess_img(frames[b], cam_small["mtx"], cam_small["dist"])
+        img = np.asarray(Image.fromarray(pre).resize((setup["iw"], setup["ih"]), Image.BILINEAR))
+        post = oracle.inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), FRAME[0], FRAME[1])
+        inst = out[b]["instances"]
+        n, rn = len(inst), int(post["boxes"].shape[0])
+        assert abs(n - rn) <= 2
+        for k in range(n):
+            tot += 1
+            if rn and float((post["boxes"] - inst.pred_boxes.tensor[k]).abs().max(dim=1).values.min()) < 2.0:
+                matched += 1
+    _log(logdir, "config3", dict(dets=tot, matched=matched))
+    assert matched >= int(0.95 * tot)              # 16-bit noise floor flips a few near-threshold candidates
