@@ -41,6 +41,8 @@ struct ConvParams {
     int cdec;
     int splitk;           // >= 1
     int steps_total;      // KH * KWCp/32
+    const void* next_w;   // filters of the NEXT layer (or nullptr): each block touches a slice so they are L2/MALL-warm
+    unsigned next_w_bytes;
     int prec;             // 0: exact f32 MFMA; 1: operands rounded to bf16 at LDS staging, f32 accumulate (f32 storage)
 };
 

@@ -59,6 +59,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     const size_t w_row = (size_t)p.KH * p.KWCp;
     const bool direct = (p.splitk == 1);
 
+    // Warm the next layer's filters: its launch starts with every block missing on the same cold lines
+    // (~1-2 us at batch 1, where a layer is only 15-60 us long).  Each block pulls a disjoint slice through
+    // its L2 while this layer's main loop runs; the values are discarded.
+    if (p.next_w && z == 0) {
+        const unsigned per_block = (p.next_w_bytes / gridDim.x + 1023u) & ~1023u;
+        const unsigned lo = blockIdx.x * per_block;
+        for (unsigned o = lo + tid * 16u; o < lo + per_block && o + 16u <= p.next_w_bytes; o += 256u * 16u) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.next_w) + o);
+            asm volatile("" ::"v"(v));
+        }
+    }
     // Persistent over tiles: the grid is min(tiles, cap); count-limited launches (packed detection
     // lists) therefore spend nothing on tiles past the device-side count.
     for (int wg = blockIdx.x; wg < nwg; wg += gridDim.x) {

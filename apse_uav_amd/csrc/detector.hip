@@ -312,10 +312,21 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
 static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t s) {
     int* total_dev = reinterpret_cast<int*>(c->res + c->lay.total);
     int* propcnt_dev = reinterpret_cast<int*>(c->res + c->lay.prop_count);
-    for (auto& st : plan) {
+    for (size_t si = 0; si < plan.size(); ++si) {
+        Step& st = plan[si];
         int rc = APSE_OK;
         if (st.kind == S_CONV) {
             ConvParams p = st.c.p;
+            // next convolution of this plan: its filters are prefetched by this launch
+            for (size_t sj = si + 1; sj < plan.size() && sj <= si + 2; ++sj)
+                if (plan[sj].kind == S_CONV) {
+                    const ConvParams& q = plan[sj].c.p;
+                    const size_t elems = (size_t)apse_roundup(q.Cout, 128) * q.KH * q.KWCp;
+                    p.next_w = q.w16 ? (const void*)q.w16 : (const void*)q.w;
+                    const size_t bytes = elems * (q.w16 ? 2 : 4);
+                    p.next_w_bytes = bytes > (64u << 20) ? (64u << 20) : (unsigned)bytes;
+                    break;
+                }
             p.B = batch * st.c.b_mult;
             p.M = p.B * p.OH * p.OW;
             p.ws = c->ws;
