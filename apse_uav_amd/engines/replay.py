@@ -1,0 +1,91 @@
+"""Lean replay of the sequential association from per-frame records.
+
+In frame-sharded runs rank 0 receives every rank's records with one gather at sequence end and must then
+run the id assignment for N x K frames on the host.  ``RcnnTracker.next_record`` + ``log_line`` do that
+through the reference-shaped containers (``Instances`` / ``ObjectInstances`` / ``WindowMask``), ~200 us per
+frame; ``FastReplay`` applies exactly the same rules on plain lists / numpy arrays (~10x cheaper), so the
+replay does not eat the scaling of an 8-GPU run.  Rules (all from the reference):
+  * first detections become objects 1..N in detection order      (dcnn/engines/rcnn_tracker.py:126-128)
+  * squared-L2 distance matrix, scipy Hungarian, ``dist < 0.6``   (:130-143)
+  * unmatched detections -> new ids, ascending detection index    (:145-147, object_instances.py:48-52)
+  * objects unseen for more than 100 frames are dropped           (:70, object_instances.py:105-125)
+  * CSV line: ids 1..max present this frame, blanks otherwise     (scripts/tests/visualize_uav.py:117-141)
+tests/test_replay.py checks it line-for-line against the RcnnTracker path.
+"""
+import numpy as np
+from scipy.optimize import linear_sum_assignment
+
+EMBEDDING_THRESHOLD = 0.6
+UNDETECTED_FRAMES_TH = 100
+
+
+class FastReplay:
+    def __init__(self, host_id):
+        self.host_id = host_id
+        self.ids, self.since, self.emb = [], [], []
+        self.next_id = 1
+        self.frame_count = 0
+        self.max_id = 0
+
+    def step(self, rec, frame_idx):
+        """Consumes one record, returns (csv_line, ids_seen_this_frame)."""
+        self.frame_count += 1
+        n = len(rec["scores"])
+        ids, since, emb = self.ids, self.since, self.emb
+        det_of = {}                                    # object slot -> detection index (this frame)
+        if n > 0:
+            E = np.asarray(rec["embeddings"], np.float32)
+            if not ids:
+                for d in range(n):
+                    ids.append(self.next_id); since.append(0); emb.append(E[d]); det_of[len(ids) - 1] = d
+                    self.next_id += 1
+            else:
+                O = np.stack(emb)
+                diff = O[:, None, :] - E[None, :, :]
+                D = (diff * diff).sum(axis=2, dtype=np.float32)
+                oi, di = linear_sum_assignment(D)
+                matched = set()
+                for o, d in zip(oi.tolist(), di.tolist()):
+                    if D[o, d] < EMBEDDING_THRESHOLD:
+                        emb[o] = E[d]; since[o] = 0; det_of[o] = d
+                        matched.add(d)
+                for d in range(n):
+                    if d not in matched:
+                        ids.append(self.next_id); since.append(0); emb.append(E[d]); det_of[len(ids) - 1] = d
+                        self.next_id += 1
+        # delete_undetected_objects(100): frames_since_detected is still last frame's value for unseen objects
+        if any(s > UNDETECTED_FRAMES_TH for s in since):
+            keep = [k for k in range(len(ids)) if not since[k] > UNDETECTED_FRAMES_TH]
+            remap = {k: j for j, k in enumerate(keep)}
+            det_of = {remap[k]: d for k, d in det_of.items() if k in remap}
+            self.ids = ids = [ids[k] for k in keep]
+            self.since = since = [since[k] for k in keep]
+            self.emb = emb = [emb[k] for k in keep]
+        seen = sorted(det_of)                          # store order == get_recent_objects order
+        # finish_association: ageing
+        for k in range(len(ids)):
+            since[k] = 0 if k in det_of else since[k] + 1
+        if not seen:
+            return "", []
+        seen_ids = [ids[k] for k in seen]
+        cent, clos = rec["centroids"], rec["closest"]
+        hi = max(seen_ids)
+        self.max_id = max(self.max_id, hi)
+        by_id = {ids[k]: det_of[k] for k in seen}
+        hdet = by_id.get(self.host_id)
+        cells = [str(frame_idx)]
+        for oid in range(1, hi + 1):
+            d = by_id.get(oid)
+            if d is None:
+                cells += ["", "", "", ""]
+                continue
+            cx, cy = int(cent[d][0]), int(cent[d][1])
+            cells.append("%d.0" % cx if cx >= 0 else "nan")
+            cells.append("%d.0" % cy if cx >= 0 else "nan")
+            if hdet is None:
+                cells += ["nan", "nan"]
+            else:
+                c = clos[d][hdet]
+                cells.append("%d.0" % int(c[0]))
+                cells.append("%d.0" % int(c[1]))
+        return ",".join(cells), seen_ids

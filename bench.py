@@ -105,6 +105,8 @@ def main():
 
     lib = _lib.load()
     records = []
+    from apse_uav_amd.engines.replay import FastReplay
+    replay = FastReplay(host_id=1)          # same association rules as RcnnTracker.next_record (tests/test_replay.py)
 
     # optional software pipeline over frames: depth contexts on depth streams (weights replicated)
     depth = max(1, args.pipeline)
@@ -153,8 +155,7 @@ def main():
         for b in range(B):
             rec = res.record(b)
             if world == 1:
-                objs = tracker.next_record(rec)
-                tracker.log_line(objs, 1, i * B + b)
+                replay.step(rec, i * B + b)
             elif timed:
                 records.append(rec)
         return res
@@ -198,9 +199,8 @@ def main():
     if dist is not None:
         allrec = gather_records(records, rank, world, dev)      # the single exchange step (RCCL over xGMI)
         if rank == 0:
-            for rec in allrec:
-                objs = tracker.next_record(rec)
-                tracker.log_line(objs, 1, tracker.frame_count - 1)
+            for k, rec in enumerate(allrec):
+                replay.step(rec, k)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -247,7 +247,7 @@ def main():
                          "whole_path_tflops": round(flops_frame * fps / world / 1e12, 3)},
         }
         if world == 1 and depth == 1 and args.throughput_depth > 1 and not args.from_host:
-            out["throughput_mode"] = throughput_mode(cfg, sd, tracker, model, frames, nres, B, args.throughput_depth)
+            out["throughput_mode"] = throughput_mode(cfg, sd, tracker, model, frames, nres, B, args.throughput_depth, replay)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, asd, host_frames, blocks, H, W, args.cpu_frames, args.cpu_threads)
         print(json.dumps(out))
@@ -255,7 +255,7 @@ def main():
         dist.destroy_process_group()
 
 
-def throughput_mode(cfg, sd, tracker, model, frames, nres, B, depth, steps=24, warmup=4):
+def throughput_mode(cfg, sd, tracker, model, frames, nres, B, depth, replay, steps=24, warmup=4):
     """Same frames, same per-frame results, `depth` frames in flight on separate streams / contexts: the
     small-grid layers of one frame (res4/res5 at batch 1 fill ~1 block per CU) overlap with other frames'.
     Informational: the headline value is the single-stream run above."""
@@ -281,8 +281,7 @@ def throughput_mode(cfg, sd, tracker, model, frames, nres, B, depth, steps=24, w
         with torch.cuda.stream(streams[k]):
             res = models[k].read(B)
         for b in range(B):
-            objs = tracker.next_record(res.record(b))
-            tracker.log_line(objs, 1, i * B + b)
+            replay.step(res.record(b), i * B + b)
 
     lat = []
     t0 = None

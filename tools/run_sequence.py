@@ -48,7 +48,14 @@ def detect_range(tracker, get_frame, lo, hi, batch, given_fn=None):
     return recs
 
 
-def replay(tracker, records, host_id, first_frame=0):
+def replay(tracker, records, host_id, first_frame=0, fast=False):
+    """Sequential id assignment over records.  fast=True: apse_uav_amd.engines.replay.FastReplay (same rules,
+    plain arrays); default: the reference-shaped RcnnTracker.next_record path."""
+    if fast:
+        from apse_uav_amd.engines.replay import FastReplay
+        fr = FastReplay(host_id)
+        lines = [fr.step(rec, first_frame + k)[0] for k, rec in enumerate(records)]
+        return lines, fr.max_id
     lines, max_id = [], 0
     for k, rec in enumerate(records):
         objs = tracker.next_record(rec)
@@ -104,7 +111,7 @@ def main(argv=None):
     if world > 1:
         recs = gather_records(recs, rank, world, torch.device("cuda", local))
     if rank == 0:
-        lines, max_id = replay(tracker, recs, args.host_id)
+        lines, max_id = replay(tracker, recs, args.host_id, fast=(world > 1))
         csv_log.write_consumer_csv(args.out, lines, args.host_id, [int(v) for v in args.vehicle_ids.split(",")])
         if args.raw_out:
             csv_log.write_raw_csv(args.raw_out, lines, args.host_id, max_id)
