@@ -89,3 +89,43 @@ class FastReplay:
                 cells.append("%d.0" % int(c[0]))
                 cells.append("%d.0" % int(c[1]))
         return ",".join(cells), seen_ids
+
+
+class NativeReplay:
+    """The same replay in C++ (``apse_replay_*`` in libapse_hip.so, host-only): a few microseconds per frame."""
+
+    def __init__(self, host_id, embed_dim=128):
+        import ctypes as C
+        from .. import _lib
+        self._C, self._lib = C, _lib.load()
+        self._h = self._lib.apse_replay_create(int(host_id), int(embed_dim), float(EMBEDDING_THRESHOLD), int(UNDETECTED_FRAMES_TH))
+        if not self._h:
+            raise _lib.ApseError("apse_replay_create failed")
+        self._buf = C.create_string_buffer(1 << 16)
+        self.edim = embed_dim
+
+    def __del__(self):
+        try:
+            self._lib.apse_replay_destroy(self._h)
+        except Exception:
+            pass
+
+    @property
+    def max_id(self):
+        return int(self._lib.apse_replay_max_id(self._h))
+
+    @property
+    def next_id(self):
+        return int(self._lib.apse_replay_next_id(self._h))
+
+    def step(self, rec, frame_idx):
+        n = len(rec["scores"])
+        emb = np.ascontiguousarray(rec["embeddings"], np.float32).reshape(n, self.edim)
+        cent = np.ascontiguousarray(rec["centroids"], np.int32).reshape(n, 2)
+        clos = np.ascontiguousarray(rec["closest"], np.int32).reshape(n, n, 2)
+        ids = np.full((max(n, 1),), -1, np.int32)
+        rc = self._lib.apse_replay_step(self._h, int(frame_idx), n, emb.ctypes.data, cent.ctypes.data, clos.ctypes.data,
+                                        self._buf, len(self._buf), ids.ctypes.data)
+        if rc < 0:
+            raise RuntimeError("apse_replay_step failed (%d)" % rc)
+        return self._buf.value.decode(), sorted(int(v) for v in ids[:n] if v > 0)

@@ -105,8 +105,8 @@ def main():
 
     lib = _lib.load()
     records = []
-    from apse_uav_amd.engines.replay import FastReplay
-    replay = FastReplay(host_id=1)          # same association rules as RcnnTracker.next_record (tests/test_replay.py)
+    from apse_uav_amd.engines.replay import NativeReplay
+    replay = NativeReplay(host_id=1)        # same association rules as RcnnTracker.next_record (tests/test_replay.py)
 
     # optional software pipeline over frames: depth contexts on depth streams (weights replicated)
     depth = max(1, args.pipeline)

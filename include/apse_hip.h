@@ -187,6 +187,17 @@ int apse_resize_normalize(const uint8_t* frames_dev, uint8_t* tmp_dev, float* ou
                           const int* hb_dev, const int* hc_dev, int hk, const int* vb_dev, const int* vc_dev, int vk, int B,
                           int H, int W, int OH, int OW, int PH, int PW, const float* mean3_host, void* stream);
 
+/* ---- host-only: native replay of the sequential association from per-frame records (rank 0 of a sharded run).
+ * Same rules as RcnnTracker.associate_detections_to_objects / ObjectInstances / generate_log_oneline
+ * (rcnn_tracker.py:122-147, object_instances.py:48-162, visualize_uav.py:117-141); no GPU is touched. */
+typedef struct apse_replay apse_replay;
+apse_replay* apse_replay_create(int host_id, int embed_dim, float dist_thresh, int max_unseen_frames);
+void apse_replay_destroy(apse_replay* r);
+int apse_replay_step(apse_replay* r, int frame_idx, int n, const float* emb_host, const int* centroid_host,
+                     const int* closest_host, char* line_out, int line_cap, int* det_ids_out);
+int apse_replay_max_id(const apse_replay* r);
+int apse_replay_next_id(const apse_replay* r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,3 +45,16 @@ def test_fast_replay_equals_tracker_path():
             assert fline == line, (t, fline, line)
             assert ids == (list(objs.ids) if len(objs) else [])
         assert fr.max_id >= 10 and fr.next_id == tr.objects.get_new_id()
+
+
+def test_native_replay_equals_fast_replay():
+    """apse_replay_* (C++ in libapse_hip.so, host-only) vs FastReplay (scipy Hungarian) on long random streams."""
+    from apse_uav_amd.engines.replay import FastReplay, NativeReplay
+    for host in (1, 4, 9):
+        fr, nr = FastReplay(host), NativeReplay(host)
+        for t, rec in enumerate(_stream(400, seed=10 + host)):
+            a, ids_a = fr.step(rec, t)
+            b, ids_b = nr.step(rec, t)
+            assert a == b, (t, a, b)
+            assert sorted(ids_a) == ids_b
+        assert fr.max_id == nr.max_id and fr.next_id == nr.next_id

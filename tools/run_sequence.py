@@ -49,11 +49,11 @@ def detect_range(tracker, get_frame, lo, hi, batch, given_fn=None):
 
 
 def replay(tracker, records, host_id, first_frame=0, fast=False):
-    """Sequential id assignment over records.  fast=True: apse_uav_amd.engines.replay.FastReplay (same rules,
-    plain arrays); default: the reference-shaped RcnnTracker.next_record path."""
+    """Sequential id assignment over records.  fast=True: apse_uav_amd.engines.replay.NativeReplay (same rules,
+    C++ in libapse_hip.so); default: the reference-shaped RcnnTracker.next_record path."""
     if fast:
-        from apse_uav_amd.engines.replay import FastReplay
-        fr = FastReplay(host_id)
+        from apse_uav_amd.engines.replay import NativeReplay
+        fr = NativeReplay(host_id)
         lines = [fr.step(rec, first_frame + k)[0] for k, rec in enumerate(records)]
         return lines, fr.max_id
     lines, max_id = [], 0
