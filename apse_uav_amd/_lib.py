@@ -100,6 +100,7 @@ def load():
         "apse_replay_create": ([i, i, f, i], vp),
         "apse_replay_destroy": ([vp], None),
         "apse_replay_step": ([vp, i, i, vp, vp, vp, C.c_char_p, i, vp], i),
+        "apse_replay_packed": ([vp, vp, i, i, i, i, vp, C.c_longlong], C.c_longlong),
         "apse_replay_max_id": ([vp], i),
         "apse_replay_next_id": ([vp], i),
         "apse_resize_normalize": ([vp, vp, vp, vp, vp, vp, i, vp, vp, i, i, i, i, i, i, i, i, C.POINTER(f * 3), vp], i),
@@ -119,7 +120,7 @@ EXPORTS = ["apse_create", "apse_destroy", "apse_last_error", "apse_version", "ap
            "apse_flops", "apse_profile", "apse_profile_read", "apse_conv_packed_elems", "apse_conv_pack_weight", "apse_conv2d", "apse_maxpool3x3s2",
            "apse_roi_align", "apse_roi_pool", "apse_nms_rank", "apse_mask_centroid_dense", "apse_mask_closest_dense",
            "apse_l2_normalize", "apse_sqdist", "apse_undistort_gamma", "apse_resize_normalize", "apse_replay_create", "apse_replay_destroy",
-           "apse_replay_step", "apse_replay_max_id", "apse_replay_next_id"]
+           "apse_replay_step", "apse_replay_packed", "apse_replay_max_id", "apse_replay_next_id"]
 
 
 def stream_ptr():

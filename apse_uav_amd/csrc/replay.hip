@@ -90,8 +90,8 @@ int apse_replay_next_id(const apse_replay* r) { return r ? r->next_id : -1; }
 // One frame.  emb [n][E] f32 (unit vectors), cent [n][2] (1-based, -1 = empty mask), closest [n][n][2].
 // Writes the CSV line (NUL-terminated) to line[0..cap) and the track id of every detection to det_ids[n].
 // Returns the line length, or a negative APSE_E_* code.
-int apse_replay_step(apse_replay* r, int frame_idx, int n, const float* emb, const int* cent, const int* closest, char* line,
-                     int cap, int* det_ids) {
+static int replay_step(apse_replay* r, int frame_idx, int n, const float* emb, const int* cent, const int* closest, int cstride,
+                       char* line, int cap, int* det_ids) {
     if (!r || n < 0 || !line || cap < 16) return APSE_E_INVALID;
     const int E = r->edim;
     const int O = (int)r->ids.size();
@@ -182,7 +182,7 @@ int apse_replay_step(apse_replay* r, int frame_idx, int n, const float* emb, con
         if (cx >= 0) { snprintf(buf, sizeof buf, ",%d.0,%d.0", cx, cy); s += buf; } else s += ",nan,nan";
         if (hdet < 0) s += ",nan,nan";
         else {
-            const int* c = closest + ((size_t)d * n + hdet) * 2;
+            const int* c = closest + ((size_t)d * cstride + hdet) * 2;
             snprintf(buf, sizeof buf, ",%d.0,%d.0", c[0], c[1]);
             s += buf;
         }
@@ -190,6 +190,44 @@ int apse_replay_step(apse_replay* r, int frame_idx, int n, const float* emb, con
     if ((int)s.size() + 1 > cap) return APSE_E_INVALID;
     memcpy(line, s.c_str(), s.size() + 1);
     return (int)s.size();
+}
+
+int apse_replay_step(apse_replay* r, int frame_idx, int n, const float* emb, const int* cent, const int* closest, char* line,
+                     int cap, int* det_ids) {
+    return replay_step(r, frame_idx, n, emb, cent, closest, n, line, cap, det_ids);
+}
+
+// Replays `nrec` records in the wire format of apse_uav_amd/sharding.py::pack_record (f32 vectors of `stride`
+// floats: [0] = n, then boxes, scores, classes, centroids, mass, rects (kd rows each), closest [kd][kd][2],
+// embeddings [kd][edim]).  Lines are written NUL-free, separated by '\n', into out[0..cap); returns the number
+// of bytes written or a negative code.
+long long apse_replay_packed(apse_replay* r, const float* recs, int nrec, int stride, int kd, int first_frame, char* out,
+                             long long cap) {
+    if (!r || !recs || !out || nrec < 0) return APSE_E_INVALID;
+    const int E = r->edim;
+    const int o_cent = 1 + kd * 4 + kd + kd, o_clos = o_cent + kd * 2 + kd + kd * 4, o_emb = o_clos + kd * kd * 2;
+    if (o_emb + kd * E > stride) return APSE_E_INVALID;
+    std::vector<int> cent((size_t)kd * 2), clos((size_t)kd * kd * 2);
+    std::vector<char> line(1 << 16);
+    long long w = 0;
+    for (int k = 0; k < nrec; ++k) {
+        const float* v = recs + (size_t)k * stride;
+        const int n = (int)v[0];
+        if (n < 0 || n > kd) return APSE_E_INVALID;
+        for (int i = 0; i < n * 2; ++i) cent[i] = (int)v[o_cent + i];
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                clos[((size_t)i * kd + j) * 2] = (int)v[o_clos + ((size_t)i * kd + j) * 2];
+                clos[((size_t)i * kd + j) * 2 + 1] = (int)v[o_clos + ((size_t)i * kd + j) * 2 + 1];
+            }
+        const int len = replay_step(r, first_frame + k, n, v + o_emb, cent.data(), clos.data(), kd, line.data(), (int)line.size(), nullptr);
+        if (len < 0) return len;
+        if (w + len + 1 > cap) return APSE_E_INVALID;
+        memcpy(out + w, line.data(), len);
+        w += len;
+        out[w++] = '\n';
+    }
+    return w;
 }
 
 }  // extern "C"

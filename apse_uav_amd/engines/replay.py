@@ -129,3 +129,15 @@ class NativeReplay:
         if rc < 0:
             raise RuntimeError("apse_replay_step failed (%d)" % rc)
         return self._buf.value.decode(), sorted(int(v) for v in ids[:n] if v > 0)
+
+    def run_packed(self, packed, kd, first_frame=0):
+        """packed: float32 array [nrec, record_len] in the gather's wire format -> list of CSV lines."""
+        packed = np.ascontiguousarray(packed, np.float32)
+        nrec, stride = packed.shape
+        cap = max(1 << 16, nrec * (64 + 48 * max(self.max_id + kd, 8)))
+        buf = self._C.create_string_buffer(cap)
+        w = self._lib.apse_replay_packed(self._h, packed.ctypes.data, nrec, stride, int(kd), int(first_frame), buf, cap)
+        if w < 0:
+            raise RuntimeError("apse_replay_packed failed (%d)" % w)
+        text = buf.raw[:w].decode()
+        return text.split("\n")[:-1] if nrec else []

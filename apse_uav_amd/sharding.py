@@ -61,7 +61,7 @@ def unpack_record(vec, kd, edim):
     return rec
 
 
-def gather_records(records, rank, world, device, kd=100, edim=128):
+def gather_records(records, rank, world, device, kd=100, edim=128, unpack=True):
     """All ranks call this once; rank 0 gets the records of every rank in rank order (frame order for
     contiguous shards), the others get None.  Ranks may hold different numbers of frames.
 
@@ -84,6 +84,9 @@ def gather_records(records, rank, world, device, kd=100, edim=128):
     if rank != 0:
         return None
     h = out.cpu().numpy().reshape(world, mx, L)
+    if not unpack:
+        # wire format kept: rank-ordered [frames, L] array for NativeReplay.run_packed
+        return np.concatenate([h[r, :counts[r]] for r in range(world)], axis=0)
     res = []
     for r in range(world):
         for i in range(counts[r]):

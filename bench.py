@@ -197,10 +197,9 @@ def main():
         account(collect(j, True))
         lat.append(time.perf_counter() - ts)
     if dist is not None:
-        allrec = gather_records(records, rank, world, dev)      # the single exchange step (RCCL over xGMI)
+        packed = gather_records(records, rank, world, dev, unpack=False)   # the single exchange step (RCCL over xGMI)
         if rank == 0:
-            for k, rec in enumerate(allrec):
-                replay.step(rec, k)
+            replay.run_packed(packed, kd=100)                              # sequential id assignment + CSV lines (C++)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -195,6 +195,10 @@ apse_replay* apse_replay_create(int host_id, int embed_dim, float dist_thresh, i
 void apse_replay_destroy(apse_replay* r);
 int apse_replay_step(apse_replay* r, int frame_idx, int n, const float* emb_host, const int* centroid_host,
                      const int* closest_host, char* line_out, int line_cap, int* det_ids_out);
+/* nrec records in the wire format of the sharded gather (apse_uav_amd/sharding.py::pack_record): one call for a
+ * whole rank's shard; lines separated by '\n'; returns bytes written. */
+long long apse_replay_packed(apse_replay* r, const float* records_host, int nrec, int stride_floats, int dets_per_image,
+                             int first_frame, char* lines_out, long long cap);
 int apse_replay_max_id(const apse_replay* r);
 int apse_replay_next_id(const apse_replay* r);
 

@@ -58,3 +58,15 @@ def test_native_replay_equals_fast_replay():
             assert a == b, (t, a, b)
             assert sorted(ids_a) == ids_b
         assert fr.max_id == nr.max_id and fr.next_id == nr.next_id
+
+
+def test_native_replay_packed_wire_format():
+    """One C call over a whole shard in the gather's wire format == per-record FastReplay."""
+    from apse_uav_amd.engines.replay import FastReplay, NativeReplay
+    from apse_uav_amd.sharding import pack_record
+    recs = _stream(120, seed=5)
+    packed = np.stack([pack_record(r, 100, 128) for r in recs])
+    fr, nr = FastReplay(2), NativeReplay(2)
+    ref = [fr.step(r, 7 + t)[0] for t, r in enumerate(recs)]
+    got = nr.run_packed(packed, kd=100, first_frame=7)
+    assert got == ref and nr.max_id == fr.max_id
