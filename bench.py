@@ -65,14 +65,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % ndev            # rehearsals may put several ranks on one GPU (APSE_DIST_BACKEND=gloo)
+    backend = os.environ.get("APSE_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     torch.cuda.set_device(dev)
 
     from apse_uav_amd import _lib
@@ -91,7 +98,7 @@ def main():
     else:
         sd = synthetic_detector_state(0, blocks, bg_bias=args.bg_bias or 0.0)
     asd = synthetic_association_state(1)
-    cfg = setup_cfg(device="cuda:%d" % local_rank)
+    cfg = setup_cfg(device="cuda:%d" % dev_index)
     cfg.APSE.MAX_BATCH = B
     cfg.APSE.DTYPE = args.dtype
     tracker = RcnnTracker(cfg, (H, W), asd, detector_state=sd)
@@ -197,7 +204,7 @@ def main():
         account(collect(j, True))
         lat.append(time.perf_counter() - ts)
     if dist is not None:
-        packed = gather_records(records, rank, world, dev, unpack=False)   # the single exchange step (RCCL over xGMI)
+        packed = gather_records(records, rank, world, coll_dev, unpack=False)   # the single exchange step (RCCL over xGMI)
         if rank == 0:
             replay.run_packed(packed, kd=100)                              # sequential id assignment + CSV lines (C++)
     torch.cuda.synchronize()
@@ -206,7 +213,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     import ctypes as C
