@@ -130,3 +130,37 @@ def test_given_boxes_csv_roundtrip(env, tmp_path):
     data = csv_log.read_centroid_data(str(path))
     assert len(data) == 4 and all(len(r) == 17 for r in data)
     assert data[0][0] == 0 and data[3][0] == 22
+
+
+def test_4k_sequence_ids_and_csv_vs_oracle(env, logdir):
+    """BASELINE config 2 in short form: a 4-frame 4K dynamic sequence through RcnnTracker.next_frame; track
+    ids per frame and the CSV line text must equal the CPU oracle's tracker (ids / integer cells exact)."""
+    from PIL import Image
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from oracle import tracker as otr
+    from oracle.detector import DetectorOracle, resize_shape
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    tr = RcnnTracker(env["cfg"], FRAME, env["asd"], detector_state=env["sd"])
+    oracle = DetectorOracle(env["sd"])
+    otk = otr.TrackerOracle()
+    ih, iw = resize_shape(*FRAME)
+    same = 0
+    for t in range(4):
+        frame = env["seq"].frame(3 * t)
+        objs = tr.next_frame(frame)
+        line, _ = tr.log_line(objs, 1, t)
+        img = np.asarray(Image.fromarray(frame).resize((iw, ih), Image.BILINEAR))
+        post = oracle.inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), *FRAME)
+        rois = otr.features_rois(post["features"]["p2"], post["boxes"], FRAME[1])
+        emb = otr.association_head(rois, env["asd"]["fc.weight"], env["asd"]["fc.bias"])
+        orec = otk.next_frame(dict(boxes=post["boxes"], scores=post["scores"], classes=post["classes"],
+                                   masks=list(zip(post["mask_windows"], post["mask_rects"])), emb=emb))
+        oline, _ = otr.log_oneline(orec, 1, t)
+        _log(logdir, "seq4k/%d" % t, dict(ids=list(objs.ids) if len(objs) else [], ref_ids=orec["ids"], same_line=line == oline))
+        assert (list(objs.ids) if len(objs) else []) == orec["ids"]
+        same += int(line == oline)
+        if line != oline:                     # a threshold-edge pixel may move one integer cell by 1
+            a, b = line.split(","), oline.split(",")
+            assert len(a) == len(b)
+            assert all(x == y or abs(float(x) - float(y)) <= 1.0 for x, y in zip(a, b))
+    assert same >= 3
