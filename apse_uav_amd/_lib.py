@@ -42,7 +42,7 @@ class ResultsLayout(C.Structure):
 
 class ConvDesc(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "relu", "res_mode",
-                                       "cfg", "splitk", "prec", "fuse_reduce")]
+                                       "cfg", "splitk", "prec", "fuse_reduce", "x_st", "res_st", "y_st")]
 
 
 _lib = None

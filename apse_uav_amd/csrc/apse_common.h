@@ -43,7 +43,8 @@ struct ConvParams {
     int steps_total;      // KH * KWCp/32
     const void* next_w;   // filters of the NEXT layer (or nullptr): each block touches a slice so they are L2/MALL-warm
     unsigned next_w_bytes;
-    int prec;             // 0: exact f32 MFMA; 1: operands rounded to bf16 at LDS staging, f32 accumulate (f32 storage)
+    int prec;             // 0: exact f32 MFMA; 1 / 2: bf16 / f16 operands (rounded at LDS staging unless stored so), f32 accumulate
+    int x_st, res_st, y_st;   // storage type of x / res / y: 0 f32, 1 bf16, 2 f16 (pointers are then 16-bit element arrays)
 };
 
 // cfg: 0=128x128 1=64x64 2=128x32 3=128x64.  ev0/ev1 (optional) are recorded right before / after the
@@ -52,6 +53,43 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0
 int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk);
 int apse_launch_conv_bf16(const ConvParams& p, int cfg, hipStream_t s);   // conv_igemm_bf16.hip
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------- typed 4-element access (device)
+// Activations are f32 or 16-bit (bf16 / f16) in HBM depending on the mode; arithmetic is always f32.
+#ifdef __HIPCC__
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 apse_ld4(const void* base, size_t idx, int st) {
+    if (st == 0) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+    f32x4 r;
+    if (st == 1) {
+        const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+        r[0] = __uint_as_float(raw.x << 16); r[1] = __uint_as_float(raw.x & 0xffff0000u);
+        r[2] = __uint_as_float(raw.y << 16); r[3] = __uint_as_float(raw.y & 0xffff0000u);
+    } else {
+        const f16x4_t h = *reinterpret_cast<const f16x4_t*>(reinterpret_cast<const uint16_t*>(base) + idx);
+        r[0] = (float)h[0]; r[1] = (float)h[1]; r[2] = (float)h[2]; r[3] = (float)h[3];
+    }
+    return r;
+}
+__device__ __forceinline__ void apse_st4(void* base, size_t idx, f32x4 v, int st) {
+    if (st == 0) { *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx) = v; return; }
+    if (st == 1) {
+        bf16x4_t b;
+        b[0] = (__bf16)v[0]; b[1] = (__bf16)v[1]; b[2] = (__bf16)v[2]; b[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<uint16_t*>(base) + idx) = b;
+    } else {
+        f16x4_t h;
+        h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+        *reinterpret_cast<f16x4_t*>(reinterpret_cast<uint16_t*>(base) + idx) = h;
+    }
+}
+__device__ __forceinline__ void apse_st1(void* base, size_t idx, float v, int st) {
+    if (st == 0) reinterpret_cast<float*>(base)[idx] = v;
+    else if (st == 1) reinterpret_cast<__bf16*>(base)[idx] = (__bf16)v;
+    else reinterpret_cast<_Float16*>(base)[idx] = (_Float16)v;
+}
+#endif
 
 // ---------------------------------------------------------------- small helpers
 static inline int apse_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (live && (unsigned)iy < (unsigned)p.H && (unsigned)px < (unsigned)p.W) {
                         const int off = ((a_pix[i] + iy * p.W + a_ix0[i]) << p.cin_log2) + q;
-                        v = *reinterpret_cast<const f32x4*>(p.x + off);
+                        v = apse_ld4(p.x, (size_t)off, p.x_st);      // 16-bit activations widen exactly to f32
                     }
                     ra[u][i] = v;
                 }
@@ -240,33 +240,32 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
         // bias + residual + ReLU + store of one float4 of output row m (the fused epilogue proper)
         auto finish = [&](f32x4 val, int m) {
             val += bias4;
-            float* dst;
+            size_t dst;                 // element index into y
             if (p.out_mode == 0) {
                 if (p.res_mode == 1) {
-                    val += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + n);
+                    val += apse_ld4(p.res, (size_t)m * p.Cout + n, p.res_st);
                 } else if (p.res_mode == 2) {
                     const int b = m / ohw;
                     const int rem = m - b * ohw;
                     const int oy = rem / p.OW, ox = rem - oy * p.OW;
                     const int hw2 = (p.OH >> 1) * (p.OW >> 1);
-                    val += *reinterpret_cast<const f32x4*>(
-                        p.res + ((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n);
+                    val += apse_ld4(p.res, ((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n, p.res_st);
                 }
-                dst = p.y + (size_t)m * p.y_ld + p.y_coff + n;
+                dst = (size_t)m * p.y_ld + p.y_coff + n;
             } else {
                 const int b = m / ohw;
                 const int rem = m - b * ohw;
                 const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                dst = p.y + (((size_t)b * 2 * p.OH + 2 * oy + (g >> 1)) * (2 * p.OW) + 2 * ox + (g & 1)) * p.cdec + co;
+                dst = (((size_t)b * 2 * p.OH + 2 * oy + (g >> 1)) * (2 * p.OW) + 2 * ox + (g & 1)) * p.cdec + co;
             }
             if (p.relu) {
                 val[0] = val[0] > 0.f ? val[0] : 0.f; val[1] = val[1] > 0.f ? val[1] : 0.f;
                 val[2] = val[2] > 0.f ? val[2] : 0.f; val[3] = val[3] > 0.f ? val[3] : 0.f;
             }
             if (vec_direct) {
-                *reinterpret_cast<f32x4*>(dst) = val;
+                apse_st4(p.y, dst, val, p.y_st);
             } else {
-                for (int k = 0; k < 4; ++k) if (n + k < p.Cout) dst[k] = val[k];
+                for (int k = 0; k < 4; ++k) if (n + k < p.Cout) apse_st1(p.y, dst + k, val[k], p.y_st);
             }
         };
         if (direct) {
@@ -344,26 +343,32 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvParams p) {
         int co = n, g = 0;
         if (p.out_mode == 1) { g = n / p.cdec; co = n - g * p.cdec; }
         if (p.bias) val += p.bias[co];
+        auto ld1 = [&](size_t idx) -> float {
+            if (p.res_st == 0) return p.res[idx];
+            if (p.res_st == 1) return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(p.res)[idx] << 16);
+            return (float)reinterpret_cast<const _Float16*>(p.res)[idx];
+        };
+        size_t dst;
         if (p.out_mode == 0) {
             if (p.res_mode == 1) {
-                val += p.res[(size_t)m * p.Cout + n];
+                val += ld1((size_t)m * p.Cout + n);
             } else if (p.res_mode == 2) {
                 const int b = m / ohw;
                 const int rem = m - b * ohw;
                 const int oy = rem / p.OW, ox = rem - oy * p.OW;
                 const int hw2 = (p.OH >> 1) * (p.OW >> 1);
-                val += p.res[((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n];
+                val += ld1(((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n);
             }
-            if (p.relu) val = val > 0.f ? val : 0.f;
-            p.y[(size_t)m * p.y_ld + p.y_coff + n] = val;
+            dst = (size_t)m * p.y_ld + p.y_coff + n;
         } else {
             const int b = m / ohw;
             const int rem = m - b * ohw;
             const int oy = rem / p.OW, ox = rem - oy * p.OW;
             const int dy = g >> 1, dx = g & 1;
-            if (p.relu) val = val > 0.f ? val : 0.f;
-            p.y[(((size_t)b * 2 * p.OH + 2 * oy + dy) * (2 * p.OW) + 2 * ox + dx) * p.cdec + co] = val;
+            dst = (((size_t)b * 2 * p.OH + 2 * oy + dy) * (2 * p.OW) + 2 * ox + dx) * p.cdec + co;
         }
+        if (p.relu) val = val > 0.f ? val : 0.f;
+        apse_st1(p.y, dst, val, p.y_st);
     }
 }
 

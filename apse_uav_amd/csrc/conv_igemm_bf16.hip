@@ -121,6 +121,19 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
 #pragma unroll
                 for (int i = 0; i < AP; ++i) {
                     const int iy = a_iy0[i] + r;
+                    if (p.x_st != 0) {
+                        // activations already stored in the operand type: one 16-byte load, no conversion
+                        // (Cin >= 8 here, so the 8 k-values of a slot belong to one pixel)
+                        et8 v;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (ET)0.f;
+                        if (qa && (unsigned)iy < (unsigned)p.H && (unsigned)(a_ix0[i] + dpa) < (unsigned)p.W) {
+                            const int off = ((a_pix[i] + iy * p.W + a_ix0[i]) << p.cin_log2) + q;
+                            v = *reinterpret_cast<const et8*>(reinterpret_cast<const ET*>(p.x) + off);
+                        }
+                        ra[u][i] = v;
+                        continue;
+                    }
                     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
                     if ((unsigned)iy < (unsigned)p.H) {
                         const int off = ((a_pix[i] + iy * p.W + a_ix0[i]) << p.cin_log2) + q;
@@ -246,33 +259,32 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
         // bias + residual + ReLU + store of one float4 of output row m (the fused epilogue proper)
         auto finish = [&](f32x4 val, int m) {
             val += bias4;
-            float* dst;
+            size_t dst;                 // element index into y
             if (p.out_mode == 0) {
                 if (p.res_mode == 1) {
-                    val += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + n);
+                    val += apse_ld4(p.res, (size_t)m * p.Cout + n, p.res_st);
                 } else if (p.res_mode == 2) {
                     const int b = m / ohw;
                     const int rem = m - b * ohw;
                     const int oy = rem / p.OW, ox = rem - oy * p.OW;
                     const int hw2 = (p.OH >> 1) * (p.OW >> 1);
-                    val += *reinterpret_cast<const f32x4*>(
-                        p.res + ((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n);
+                    val += apse_ld4(p.res, ((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n, p.res_st);
                 }
-                dst = p.y + (size_t)m * p.y_ld + p.y_coff + n;
+                dst = (size_t)m * p.y_ld + p.y_coff + n;
             } else {
                 const int b = m / ohw;
                 const int rem = m - b * ohw;
                 const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                dst = p.y + (((size_t)b * 2 * p.OH + 2 * oy + (g >> 1)) * (2 * p.OW) + 2 * ox + (g & 1)) * p.cdec + co;
+                dst = (((size_t)b * 2 * p.OH + 2 * oy + (g >> 1)) * (2 * p.OW) + 2 * ox + (g & 1)) * p.cdec + co;
             }
             if (p.relu) {
                 val[0] = val[0] > 0.f ? val[0] : 0.f; val[1] = val[1] > 0.f ? val[1] : 0.f;
                 val[2] = val[2] > 0.f ? val[2] : 0.f; val[3] = val[3] > 0.f ? val[3] : 0.f;
             }
             if (vec_direct) {
-                *reinterpret_cast<f32x4*>(dst) = val;
+                apse_st4(p.y, dst, val, p.y_st);
             } else {
-                for (int k = 0; k < 4; ++k) if (n + k < p.Cout) dst[k] = val[k];
+                for (int k = 0; k < 4; ++k) if (n + k < p.Cout) apse_st1(p.y, dst + k, val[k], p.y_st);
             }
         };
         if (direct) {

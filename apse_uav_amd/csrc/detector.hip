@@ -1022,6 +1022,10 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
     p.M = p.B * p.OH * p.OW; p.m_per_item = p.OH * p.OW;
     p.y_ld = d->Cout; p.steps_total = p.KH * (p.KWCp / 32);
     p.prec = (d->prec == 1 || d->prec == 2) ? d->prec : 0;
+    p.x_st = d->x_st; p.res_st = d->res_st; p.y_st = d->y_st;
+    if (p.x_st < 0 || p.x_st > 2 || p.res_st < 0 || p.res_st > 2 || p.y_st < 0 || p.y_st > 2) return APSE_E_INVALID;
+    if (p.prec && p.x_st && p.x_st != p.prec) return APSE_E_INVALID;       // 16-bit x must already be the operand type
+    if (p.x_st && cin_p < 8) return APSE_E_INVALID;
     int sk = 1;
     int cfg = apse_conv_pick_cfg(p.M, p.Cout, p.steps_total, &sk);
     if (d->cfg >= 0) { cfg = d->cfg; sk = 1; }

@@ -154,6 +154,8 @@ typedef struct apse_conv_desc {
     int splitk;             /* 0 auto */
     int prec;               /* 0 f32 MFMA; 1 bf16 / 2 f16 MFMA (operands rounded at LDS staging, f32 accumulate) */
     int fuse_reduce;        /* split-K: 1 = last-arriving block reduces in the launch, 0 = separate reduce kernel */
+    int x_st, res_st, y_st; /* storage type of x / residual / y: 0 f32, 1 bf16, 2 f16 (16-bit tensors need C % 8 == 0;
+                               with prec 1/2 a 16-bit x must be stored in the operand type) */
 } apse_conv_desc;
 size_t apse_conv_packed_elems(const apse_conv_desc* d);
 /* OIHW host filter (+ optional per-channel scale) -> packed host filter for apse_conv2d. */

@@ -15,7 +15,7 @@ def to_nhwc(x, cpad=None):
 
 
 def hip_conv2d(x_nchw, w_oihw, bias=None, stride=1, pad=0, relu=False, residual=None, res_mode=0, cfg=-1, splitk=0,
-               scale=None, prec=0, fuse=0):
+               scale=None, prec=0, fuse=0, x_st=0, res_st=0, y_st=0):
     """x: CPU NCHW f32; returns CPU NCHW f32 computed by apse_conv2d on cuda:0."""
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -28,6 +28,8 @@ def hip_conv2d(x_nchw, w_oihw, bias=None, stride=1, pad=0, relu=False, residual=
     d.B, d.H, d.W, d.Cin = B, H, W, cin_p
     d.Cout, d.KH, d.KW, d.stride, d.pad = Cout, KH, KW, stride, pad
     d.relu, d.res_mode, d.cfg, d.splitk, d.prec, d.fuse_reduce = int(relu), res_mode, cfg, splitk, prec, fuse
+    d.x_st, d.res_st, d.y_st = x_st, res_st, y_st
+    tdt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
     packed = np.zeros(lib.apse_conv_packed_elems(C.byref(d)), np.float32)
     w = np.ascontiguousarray(w_oihw.numpy(), np.float32)
     sc = None if scale is None else np.ascontiguousarray(scale.numpy(), np.float32)
@@ -36,21 +38,21 @@ def hip_conv2d(x_nchw, w_oihw, bias=None, stride=1, pad=0, relu=False, residual=
     bias_p = torch.zeros(((Cout + 127) // 128) * 128)
     if bias is not None:
         bias_p[:Cout] = bias
-    xd = to_nhwc(x_nchw, cin_p).to(dev)
+    xd = to_nhwc(x_nchw, cin_p).to(dev).to(tdt[x_st]).contiguous()
     wd = torch.from_numpy(packed).to(dev)
     bd = bias_p.to(dev)
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
-    y = torch.full((B, OH, OW, Cout), float("nan"), device=dev)
+    y = torch.full((B, OH, OW, Cout), float("nan"), device=dev, dtype=tdt[y_st])
     rd = None
     if residual is not None:
-        rd = to_nhwc(residual).to(dev)
+        rd = to_nhwc(residual).to(dev).to(tdt[res_st]).contiguous()
     ws = torch.empty((64 * B * OH * OW * Cout + 16,), device=dev)
     rc = lib.apse_conv2d(C.byref(d), _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y), _lib.ptr(ws),
                          ws.numel() * 4, _lib.stream_ptr())
     assert rc == 0, "apse_conv2d rc=%d" % rc
     torch.cuda.synchronize()
-    return y.cpu().permute(0, 3, 1, 2).contiguous()
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
 
 
 def err_stats(a, b):

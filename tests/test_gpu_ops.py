@@ -114,6 +114,48 @@ def test_conv2d_fused_splitk(shape, prec, logdir):
         assert torch.equal(out, ref), (rep, float((out - ref).abs().max()))
 
 
+@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[2] >= 8], ids=[c[0] for c in CONV_CASES if c[2] >= 8])
+def test_conv2d_16bit_storage(case, prec, logdir):
+    """16-bit STORAGE mode: activations, residual and output live in HBM as bf16 / f16; operands go to the
+    matrix cores without conversion, accumulation is f32, the output is rounded once at the store."""
+    from hip_helpers import hip_conv2d, err_stats
+    import zlib
+    name, B, Cin, H, W, Cout, K, stride, pad, relu, res_mode, cfg, splitk = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    dt = torch.bfloat16 if prec == 1 else torch.float16
+    r16 = lambda t: t.to(dt).to(torch.float32)
+    x = r16(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, r16(w), b, stride=stride, padding=pad)
+    res = None
+    if res_mode == 1:
+        res = r16(torch.randn(ref.shape, generator=g))
+        ref = ref + res
+    elif res_mode == 2:
+        res = r16(torch.randn(B, Cout, ref.shape[2] // 2, ref.shape[3] // 2, generator=g))
+        ref = ref + F.interpolate(res, scale_factor=2, mode="nearest")
+    if relu:
+        ref = F.relu(ref)
+    out = hip_conv2d(x, w, b, stride, pad, relu, res, res_mode, cfg, splitk, prec=prec, x_st=prec, res_st=prec if res is not None else 0,
+                     y_st=prec)
+    # the kernel's f32 result differs from the reference's by summation order only; after the 16-bit store the two
+    # agree except where that tiny difference straddles a rounding boundary (then by one 16-bit ulp)
+    ulp = 2.0 ** (-7 if prec == 1 else -10)        # one unit in the last place, relative to the binade's lower edge
+    diff = (out - r16(ref)).abs()
+    tol = ulp * ref.abs().clamp_min(1e-3) * 1.01 + 1e-6
+    frac = float((diff > 1e-6 * ref.abs().clamp_min(1.0)).float().mean())
+    _log(logdir, "conv_16bit_storage/%d/" % prec + name, dict(max=float(diff.max()), frac_differs=frac))
+    assert bool((diff <= tol).all()) and frac < 0.02
+    # f32-compute kernel reading 16-bit activations (decision layers in 16-bit storage mode)
+    if cfg in (-1, 2) and res_mode == 0:
+        out32 = hip_conv2d(x, w, b, stride, pad, relu, None, 0, cfg, splitk, prec=0, x_st=prec)
+        ref32 = F.conv2d(x, w, b, stride=stride, padding=pad)
+        ref32 = F.relu(ref32) if relu else ref32
+        assert err_stats(out32, ref32)["rel_to_max"] < 2e-5
+
+
 def test_maxpool(logdir):
     from apse_uav_amd import _lib
     from hip_helpers import to_nhwc
