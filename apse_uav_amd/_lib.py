@@ -29,7 +29,7 @@ class Config(C.Structure):
         ("score_thresh", C.c_float), ("box_nms", C.c_float), ("rpn_nms", C.c_float), ("mask_thresh", C.c_float),
         ("rpn_pre_topk", C.c_int), ("rpn_post_topk", C.c_int), ("dets_per_image", C.c_int),
         ("pixel_mean", C.c_float * 3), ("assoc_roi", C.c_int), ("embed_dim", C.c_int), ("assoc_scale", C.c_float),
-        ("compute_dtype", C.c_int),
+        ("compute_dtype", C.c_int), ("storage16", C.c_int),
     ]
 
 

@@ -17,7 +17,7 @@
 struct RpnLevel { const float* head; int H, W, stride; int n; int k; float base[3][4]; };
 struct RpnLevels { RpnLevel lv[5]; int head_ld; int pre_topk; };
 struct TopkJob { int kind; int level; int begin, count; int nsrc; int src[4]; int src_count[4]; int dst; int dst_count; };
-struct FpnMaps { const float* p[4]; int H[4], W[4]; float scale[4]; };
+struct FpnMaps { const void* p[4]; int H[4], W[4]; float scale[4]; int st; };
 struct PasteParams {
     const float* boxes; const int* cls; const int* total; const float* logits; int M, ldc; float sx, sy; int out_h, out_w;
     int words_per_row; float thresh; float* boxes_out; int* valid; int* rect; uint64_t* bits; unsigned long long* sums;
@@ -26,9 +26,9 @@ extern "C" {
 int apse_k_pil_resize(const uint8_t*, uint8_t*, float*, uint8_t*, const int*, const int*, int, const int*, const int*, int, int,
                       int, int, int, int, int, int, const float*, hipStream_t);
 int apse_k_chw_norm(const float*, float*, int, int, int, int, int, const float*, hipStream_t);
-int apse_k_maxpool3x3s2(const float*, float*, int, int, int, int, hipStream_t);
-int apse_k_subsample2(const float*, float*, int, int, int, int, hipStream_t);
-int apse_k_nhwc_to_nchw(const float*, float*, int, int, int, hipStream_t);
+int apse_k_maxpool3x3s2(const void*, void*, int, int, int, int, int, hipStream_t);
+int apse_k_subsample2(const void*, void*, int, int, int, int, int, hipStream_t);
+int apse_k_nhwc_to_nchw(const void*, float*, int, int, int, int, hipStream_t);
 int apse_k_rpn_topk_stage(const RpnLevels*, const TopkJob*, int, uint64_t*, int, int, uint32_t*, hipStream_t);
 int apse_k_rpn_decode(const RpnLevels*, int, const uint64_t*, int, const int*, float, float, float, float*, float*, int*,
                       uint32_t*, int, int, hipStream_t);
@@ -41,8 +41,8 @@ int apse_k_box_candidates(const float*, int, int, const float*, const int*, int,
                           float*, float*, int*, uint32_t*, float*, int, hipStream_t);
 int apse_k_pack_detections(const float*, const float*, const int*, const int*, int, int, int, float*, float*, int*, int*,
                            int*, int*, int*, hipStream_t);
-int apse_k_roi_align(const FpnMaps*, const float*, const int*, const int*, const int*, int, int, int, float*, hipStream_t);
-int apse_k_roi_pool(const float*, int, int, const float*, const int*, const int*, int, int, float, float*, hipStream_t);
+int apse_k_roi_align(const FpnMaps*, const float*, const int*, const int*, const int*, int, int, int, void*, int, hipStream_t);
+int apse_k_roi_pool(const void*, int, int, int, const float*, const int*, const int*, int, int, float, float*, hipStream_t);
 int apse_k_l2_normalize(const float*, float*, int, const int*, int, hipStream_t);
 int apse_k_sqdist(const float*, const float*, int, int, int, float*, hipStream_t);
 int apse_k_mask_paste(const PasteParams*, int, int*, int*, hipStream_t);
@@ -59,7 +59,7 @@ static std::string g_create_error;
 #define NMS_SLOT 1024
 
 struct HostW { std::vector<float> v; std::vector<int64_t> shape; };
-struct Tens { float* p = nullptr; int H = 0, W = 0, C = 0; };   // per-item NHWC dims
+struct Tens { float* p = nullptr; int H = 0, W = 0, C = 0; int st = 0; };   // per-item NHWC dims; st: 0 f32, 1 bf16, 2 f16 storage
 
 struct ConvStep {
     ConvParams p;          // B/M filled at launch
@@ -70,7 +70,7 @@ struct ConvStep {
     std::string name;
 };
 enum StepKind { S_CONV, S_MAXPOOL, S_SUBSAMPLE };
-struct Step { StepKind kind; ConvStep c; const float* x; float* y; int H, W, C; };
+struct Step { StepKind kind; ConvStep c; const float* x; float* y; int H, W, C; int st = 0; };
 
 struct apse_ctx {
     apse_config cfg;
@@ -154,10 +154,11 @@ static const HostW* getw(apse_ctx* c, const std::string& n) {
     return it == c->hw.end() ? nullptr : &it->second;
 }
 
-static Tens make_t(apse_ctx* c, const std::string& name, int items, int H, int W, int C) {
+static Tens make_t(apse_ctx* c, const std::string& name, int items, int H, int W, int C, int st = 0) {
     Tens t;
-    t.H = H; t.W = W; t.C = C;
-    t.p = dalloc<float>(c, (size_t)items * H * W * C);
+    t.H = H; t.W = W; t.C = C; t.st = st;
+    const size_t elems = (size_t)items * H * W * C;
+    t.p = dalloc<float>(c, st ? (elems + 1) / 2 : elems);          // 16-bit storage: half the bytes
     c->t[name] = t;
     return t;
 }
@@ -171,8 +172,12 @@ struct ConvSpec {
     int deconv = 0;
 };
 
+// 16-bit storage mode: every activation the bulk GEMMs produce lives in HBM in the operand type; the narrow
+// decision heads (Cout <= 32) and the association FC keep f32 outputs.
+static int storage_type(const apse_ctx* c) { return (c->cfg.compute_dtype >= 1 && c->cfg.storage16) ? c->cfg.compute_dtype : 0; }
+
 static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, const Tens& in, int in_items_mult, Tens* out,
-                    const std::string& out_name, const float* res, int res_mode, int y_ld_override, int count_kind,
+                    const std::string& out_name, const Tens* res, int res_mode, int y_ld_override, int count_kind,
                     float* out_ptr_override = nullptr) {
     // gather rows
     std::vector<float> rows;    // OIHW concatenated
@@ -274,7 +279,8 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     cs.b_mult = in_items_mult;
     cs.count_kind = count_kind;
     ConvParams& p = cs.p;
-    p.x = in.p; p.w = wd; p.w16 = wd16; p.bias = bd; p.res = res; p.res_mode = res_mode;
+    p.x = in.p; p.w = wd; p.w16 = wd16; p.bias = bd; p.res = res ? res->p : nullptr; p.res_mode = res_mode;
+    p.x_st = in.st; p.res_st = res ? res->st : 0;
     p.H = in.H; p.W = in.W; p.cin_log2 = apse_ilog2(cin_p);
     p.KH = KH; p.KW = KW; p.stride = sp.stride; p.pad = sp.pad; p.KWCp = KWCp;
     p.OH = (in.H + 2 * sp.pad - KH) / sp.stride + 1;
@@ -288,9 +294,12 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     p.cdec = sp.deconv ? Cout / 4 : 0;
     const int out_c = sp.deconv ? Cout / 4 : (y_ld_override > 0 ? y_ld_override : Cout);
     const int oh = sp.deconv ? 2 * p.OH : p.OH, ow = sp.deconv ? 2 * p.OW : p.OW;
+    const int out_st = (use_bf16 && !out_ptr_override) ? storage_type(c) : 0;
+    if (out_st && (out_c & 7)) return fail(c, APSE_E_INVALID, "16-bit tensors need C % 8 == 0 at " + sp.name);
     Tens o;
     if (out_ptr_override) { o.p = out_ptr_override; o.H = oh; o.W = ow; o.C = out_c; }
-    else o = make_t(c, out_name, c->cfg.max_batch * in_items_mult, oh, ow, out_c);
+    else o = make_t(c, out_name, c->cfg.max_batch * in_items_mult, oh, ow, out_c, out_st);
+    p.y_st = o.st;
     if (!o.p) return fail(c, APSE_E_NOMEM, "activation alloc failed at " + sp.name);
     p.y = o.p; p.y_ld = out_c; p.y_coff = 0;
     cs.flops_per_item = 2.0 * p.OH * p.OW * (double)Cout * KH * KW * Cin;
@@ -359,9 +368,9 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
             rc = apse_launch_conv(p, cfg, s, e0 >= 0 ? c->ev_pool[e0] : nullptr, e0 >= 0 ? c->ev_pool[e0 + 1] : nullptr);
             if (e0 >= 0) c->pending.push_back({cfg, st.c.flops_per_item, st.c.count_kind, st.c.b_mult, batch, e0, e0 + 1});
         } else if (st.kind == S_MAXPOOL) {
-            rc = apse_k_maxpool3x3s2(st.x, st.y, batch, st.H, st.W, st.C, s);
+            rc = apse_k_maxpool3x3s2(st.x, st.y, batch, st.H, st.W, st.C, st.st, s);
         } else {
-            rc = apse_k_subsample2(st.x, st.y, batch, st.H, st.W, st.C, s);
+            rc = apse_k_subsample2(st.x, st.y, batch, st.H, st.W, st.C, st.st, s);
         }
         if (rc != APSE_OK) return fail(c, rc, "launch failed at step " + st.c.name);
     }
@@ -404,8 +413,8 @@ static int build_plan(apse_ctx* c) {
     if (rc) return rc;
     {
         Step st; st.kind = S_MAXPOOL; st.x = cur.p; st.H = cur.H; st.W = cur.W; st.C = cur.C;
-        Tens o = make_t(c, "stem", B, (cur.H + 2 - 3) / 2 + 1, (cur.W + 2 - 3) / 2 + 1, cur.C);
-        st.y = o.p; st.c.name = "stem.pool";
+        Tens o = make_t(c, "stem", B, (cur.H + 2 - 3) / 2 + 1, (cur.W + 2 - 3) / 2 + 1, cur.C, cur.st);
+        st.y = o.p; st.c.name = "stem.pool"; st.st = cur.st;
         c->backbone.push_back(st);
         cur = o;
     }
@@ -418,12 +427,12 @@ static int build_plan(apse_ctx* c) {
             const std::string P = pre;
             const int stride = (bi == 0 && si > 0) ? 2 : 1;
             Tens a, b2, sc, out;
-            const float* resp = cur.p;
+            const Tens* resp = &cur;
             if (getw(c, P + ".shortcut.weight")) {
                 rc = add_conv(c, c->backbone, ConvSpec{P + ".shortcut", {P + ".shortcut"}, 1, 1, stride, 0, 0}, cur, 1, &sc,
                               P + ".shortcut", nullptr, 0, 0, 0);
                 if (rc) return rc;
-                resp = sc.p;
+                resp = &sc;
             }
             rc = add_conv(c, c->backbone, ConvSpec{P + ".conv1", {P + ".conv1"}, 1, 1, stride, 0, 1}, cur, 1, &a, P + ".conv1",
                           nullptr, 0, 0, 0);
@@ -449,7 +458,7 @@ static int build_plan(apse_ctx* c) {
         snprintf(pn, sizeof pn, "p%d", lvl);
         Tens ninner;
         rc = add_conv(c, c->backbone, ConvSpec{ln, {ln}, 1, 1, 1, 0, 0}, c->t[rn], 1, &ninner, in_name,
-                      lvl == 5 ? nullptr : inner.p, lvl == 5 ? 0 : 2, 0, 0);
+                      lvl == 5 ? nullptr : &inner, lvl == 5 ? 0 : 2, 0, 0);
         if (rc) return rc;
         inner = ninner;
         rc = add_conv(c, c->backbone, ConvSpec{on, {on}, 3, 3, 1, 1, 0}, inner, 1, &pl[lvl - 2], pn, nullptr, 0, 0, 0);
@@ -457,8 +466,8 @@ static int build_plan(apse_ctx* c) {
     }
     {
         Step st; st.kind = S_SUBSAMPLE; st.x = pl[3].p; st.H = pl[3].H; st.W = pl[3].W; st.C = 256;
-        pl[4] = make_t(c, "p6", B, (pl[3].H - 1) / 2 + 1, (pl[3].W - 1) / 2 + 1, 256);
-        st.y = pl[4].p; st.c.name = "p6";
+        pl[4] = make_t(c, "p6", B, (pl[3].H - 1) / 2 + 1, (pl[3].W - 1) / 2 + 1, 256, pl[3].st);
+        st.y = pl[4].p; st.c.name = "p6"; st.st = pl[3].st;
         c->backbone.push_back(st);
     }
     // ---- RPN head per level: conv3x3+relu, fused 1x1 (3 objectness + 12 deltas) -> ld 16
@@ -552,7 +561,8 @@ static int build_plan(apse_ctx* c) {
     c->prop_entry = dalloc<int>(c, (size_t)B * POST);
     // ---- box head: ROIAlign 7x7 -> fc1 (7x7 valid conv) -> fc2 -> fused predictor (K+1 logits, 4K deltas), ld 32
     for (int l = 0; l < 4; ++l) { c->fm.p[l] = pl[l].p; c->fm.H[l] = pl[l].H; c->fm.W[l] = pl[l].W; c->fm.scale[l] = 1.0f / (float)strides[l]; }
-    Tens pooled = make_t(c, "box_pooled", B * POST, 7, 7, 256);
+    c->fm.st = pl[0].st;
+    Tens pooled = make_t(c, "box_pooled", B * POST, 7, 7, 256, storage_type(c));
     Tens f1, f2, pr;
     rc = add_conv(c, c->boxhead, ConvSpec{"box_fc1", {"roi_heads.box_head.fc1"}, 7, 7, 1, 0, 1, 7, 7}, pooled, POST, &f1, "box_fc1",
                   nullptr, 0, 0, 1);
@@ -575,7 +585,7 @@ static int build_plan(apse_ctx* c) {
     c->det_cnt = dalloc<int>(c, (size_t)B);
     // ---- mask head on the packed detection list
     const int NM = B * KD;
-    Tens mp = make_t(c, "mask_pooled", NM, 14, 14, 256);
+    Tens mp = make_t(c, "mask_pooled", NM, 14, 14, 256, storage_type(c));
     Tens m = mp, md, ml;
     for (int i = 1; i <= 4; ++i) {
         char nm[48], wn[64];
@@ -760,7 +770,8 @@ int apse_box_head(apse_ctx* c, int batch, void* stream) {
     const apse_config& g = c->cfg;
     int* propcnt = reinterpret_cast<int*>(c->res + c->lay.prop_count);
     const int P = g.rpn_post_topk, K = g.num_classes;
-    int rc = apse_k_roi_align(&c->fm, c->props, nullptr, propcnt, nullptr, P, batch * P, 7, c->t["box_pooled"].p, s);
+    int rc = apse_k_roi_align(&c->fm, c->props, nullptr, propcnt, nullptr, P, batch * P, 7, c->t["box_pooled"].p,
+                              c->t["box_pooled"].st, s);
     if (rc) return fail(c, rc, "roi_align(7) launch failed");
     rc = run_plan(c, c->boxhead, batch, s);
     if (rc) return rc;
@@ -817,7 +828,7 @@ int apse_mask_tail(apse_ctx* c, int batch, void* stream) {
     const int NM = batch * g.dets_per_image;
     int* total = (int*)(r + c->lay.total);
     int rc = apse_k_roi_align(&c->fm, (float*)(r + c->lay.box_resized), (int*)(r + c->lay.img), nullptr, total, 0, NM, 14,
-                              c->t["mask_pooled"].p, s);
+                              c->t["mask_pooled"].p, c->t["mask_pooled"].st, s);
     if (rc) return fail(c, rc, "roi_align(14) launch failed");
     rc = run_plan(c, c->maskhead, batch, s);
     if (rc) return rc;
@@ -844,7 +855,7 @@ int apse_embed(apse_ctx* c, int batch, void* stream) {
     const int NM = batch * g.dets_per_image;
     int* total = (int*)(r + c->lay.total);
     const Tens& p2 = c->t["p2"];
-    int rc = apse_k_roi_pool(p2.p, p2.H, p2.W, (float*)(r + c->lay.box), (int*)(r + c->lay.img), total, NM, g.assoc_roi,
+    int rc = apse_k_roi_pool(p2.p, p2.st, p2.H, p2.W, (float*)(r + c->lay.box), (int*)(r + c->lay.img), total, NM, g.assoc_roi,
                              g.assoc_scale, c->t["assoc_pooled"].p, s);
     if (rc) return fail(c, rc, "roi_pool launch failed");
     rc = run_plan(c, c->embedfc, batch, s);
@@ -939,7 +950,7 @@ int apse_export_feature(apse_ctx* c, const char* name, float* dst, int batch, vo
     auto it = c->t.find(name);
     if (it == c->t.end()) return fail(c, APSE_E_MISSING, std::string("no tensor ") + name);
     const Tens& t = it->second;
-    int rc = apse_k_nhwc_to_nchw(t.p, dst, batch, t.H * t.W, t.C, (hipStream_t)stream);
+    int rc = apse_k_nhwc_to_nchw(t.p, dst, batch, t.H * t.W, t.C, t.st, (hipStream_t)stream);
     return rc ? fail(c, rc, "export launch failed") : APSE_OK;
 }
 
@@ -970,7 +981,7 @@ int apse_debug_tensor(apse_ctx* c, const char* name, void* dst, size_t max_bytes
         int items = B;
         if (nm == "box_pooled" || nm == "box_fc1" || nm == "box_fc2" || nm == "box_pred") items = B * g.rpn_post_topk;
         else if (nm.rfind("mask_", 0) == 0 || nm.rfind("assoc_", 0) == 0) items = B * g.dets_per_image;
-        src = t.p; n = (size_t)items * t.H * t.W * t.C * 4;
+        src = t.p; n = (size_t)items * t.H * t.W * t.C * (t.st ? 2 : 4);
     }
     if (bytes) *bytes = n;
     if (!dst) return APSE_OK;
@@ -1042,7 +1053,7 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
 }
 
 int apse_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream) {
-    return apse_k_maxpool3x3s2(x, y, B, H, W, C, (hipStream_t)stream);
+    return apse_k_maxpool3x3s2(x, y, B, H, W, C, 0, (hipStream_t)stream);
 }
 
 int apse_roi_align(const float* const* feats, const int* hs, const int* ws, const float* rois, int n, int per_img, int out_size,
@@ -1050,6 +1061,7 @@ int apse_roi_align(const float* const* feats, const int* hs, const int* ws, cons
     FpnMaps F;
     static const float sc[4] = {0.25f, 0.125f, 0.0625f, 0.03125f};
     for (int l = 0; l < 4; ++l) { F.p[l] = feats[l]; F.H[l] = hs[l]; F.W[l] = ws[l]; F.scale[l] = sc[l]; }
+    F.st = 0;
     // all rois live: a one-element count array is not available here, so use a device int holding n via total
     static int* total_dev = nullptr;
     if (!total_dev) hipMalloc(reinterpret_cast<void**>(&total_dev), sizeof(int));
@@ -1061,7 +1073,7 @@ int apse_roi_align(const float* const* feats, const int* hs, const int* ws, cons
     int* img_dev = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&img_dev), sizeof(int) * (n > 0 ? n : 1)) != hipSuccess) return APSE_E_NOMEM;
     hipMemcpy(img_dev, img.data(), sizeof(int) * n, hipMemcpyHostToDevice);
-    int rc = apse_k_roi_align(&F, rois, img_dev, nullptr, total_dev, 0, n, out_size, out, (hipStream_t)stream);
+    int rc = apse_k_roi_align(&F, rois, img_dev, nullptr, total_dev, 0, n, out_size, out, 0, (hipStream_t)stream);
     hipStreamSynchronize((hipStream_t)stream);
     hipFree(img_dev);
     return rc;
@@ -1073,7 +1085,7 @@ int apse_roi_pool(const float* feat, int H, int W, const float* rois, const int*
     if (!total_dev) hipMalloc(reinterpret_cast<void**>(&total_dev), sizeof(int));
     hipMemcpyAsync(total_dev, &n, sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream);
     hipStreamSynchronize((hipStream_t)stream);
-    return apse_k_roi_pool(feat, H, W, rois, roi_img, total_dev, n, out_size, scale, out, (hipStream_t)stream);
+    return apse_k_roi_pool(feat, 0, H, W, rois, roi_img, total_dev, n, out_size, scale, out, (hipStream_t)stream);
 }
 
 int apse_nms_rank(const float* boxes, const float* scores, const int* valid, int n, int cat_div, int cat_mod, int ncat, float thr,

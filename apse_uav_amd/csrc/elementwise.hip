@@ -76,9 +76,9 @@ __global__ __launch_bounds__(256) void chw_to_nhwc4_norm(const float* __restrict
     *reinterpret_cast<f32x4*>(out + (((size_t)b * PH + oy) * PW + ox) * 4) = v;
 }
 
-// max_pool2d(k=3, s=2, p=1) on NHWC f32, C % 4 == 0.  One thread per (pixel, 4 channels).
-__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* __restrict__ x, float* __restrict__ y, int B, int H,
-                                                         int W, int C, int OH, int OW) {
+// max_pool2d(k=3, s=2, p=1) on NHWC (f32 or 16-bit storage), C % 4 == 0.  One thread per (pixel, 4 channels).
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const void* __restrict__ x, void* __restrict__ y, int B, int H,
+                                                         int W, int C, int OH, int OW, int st) {
     const int c4 = C >> 2;
     const size_t total = (size_t)B * OH * OW * c4;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -95,20 +95,20 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc(const float* __restrict
             for (int dx = 0; dx < 3; ++dx) {
                 const int ix = ox * 2 - 1 + dx;
                 if ((unsigned)ix >= (unsigned)W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + c * 4);
+                const f32x4 v = apse_ld4(x, (((size_t)b * H + iy) * W + ix) * C + c * 4, st);
                 m[0] = v[0] > m[0] ? v[0] : m[0];
                 m[1] = v[1] > m[1] ? v[1] : m[1];
                 m[2] = v[2] > m[2] ? v[2] : m[2];
                 m[3] = v[3] > m[3] ? v[3] : m[3];
             }
         }
-        *reinterpret_cast<f32x4*>(y + (((size_t)b * OH + oy) * OW + ox) * C + c * 4) = m;
+        apse_st4(y, (((size_t)b * OH + oy) * OW + ox) * C + c * 4, m, st);
     }
 }
 
 // max_pool2d(k=1, s=2): p6 = p5[:, ::2, ::2]
-__global__ __launch_bounds__(256) void subsample2_nhwc(const float* __restrict__ x, float* __restrict__ y, int B, int H,
-                                                       int W, int C, int OH, int OW) {
+__global__ __launch_bounds__(256) void subsample2_nhwc(const void* __restrict__ x, void* __restrict__ y, int B, int H,
+                                                       int W, int C, int OH, int OW, int st) {
     const int c4 = C >> 2;
     const size_t total = (size_t)B * OH * OW * c4;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -118,20 +118,27 @@ __global__ __launch_bounds__(256) void subsample2_nhwc(const float* __restrict__
         pix /= OW;
         const int oy = (int)(pix % OH);
         const int b = (int)(pix / OH);
-        *reinterpret_cast<f32x4*>(y + (((size_t)b * OH + oy) * OW + ox) * C + c * 4) =
-            *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c * 4);
+        apse_st4(y, (((size_t)b * OH + oy) * OW + ox) * C + c * 4,
+                 apse_ld4(x, (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c * 4, st), st);
     }
 }
 
 // NHWC -> NCHW copy (exposes p2..p6 in the layout the reference API returns).
-__global__ __launch_bounds__(256) void nhwc_to_nchw(const float* __restrict__ x, float* __restrict__ y, int B, int HW, int C) {
+__global__ __launch_bounds__(256) void nhwc_to_nchw(const void* __restrict__ x, float* __restrict__ y, int B, int HW, int C, int st) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int i = ty; i < 32; i += 8) {
         const int p = p0 + i, c = c0 + tx;
-        tile[i][tx] = (p < HW && c < C) ? x[((size_t)b * HW + p) * C + c] : 0.f;
+        float v = 0.f;
+        if (p < HW && c < C) {
+            const size_t idx = ((size_t)b * HW + p) * C + c;
+            if (st == 0) v = reinterpret_cast<const float*>(x)[idx];
+            else if (st == 1) v = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(x)[idx] << 16);
+            else v = (float)reinterpret_cast<const _Float16*>(x)[idx];
+        }
+        tile[i][tx] = v;
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
@@ -156,24 +163,24 @@ int apse_k_chw_norm(const float* img, float* out, int B, int OH, int OW, int PH,
                        mean[1], mean[2]);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
-int apse_k_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, hipStream_t s) {
+int apse_k_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int st, hipStream_t s) {
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     size_t total = (size_t)B * OH * OW * (C / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(maxpool3x3s2_nhwc, dim3(blocks), dim3(256), 0, s, x, y, B, H, W, C, OH, OW);
+    hipLaunchKernelGGL(maxpool3x3s2_nhwc, dim3(blocks), dim3(256), 0, s, x, y, B, H, W, C, OH, OW, st);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
-int apse_k_subsample2(const float* x, float* y, int B, int H, int W, int C, hipStream_t s) {
+int apse_k_subsample2(const void* x, void* y, int B, int H, int W, int C, int st, hipStream_t s) {
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
     size_t total = (size_t)B * OH * OW * (C / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(subsample2_nhwc, dim3(blocks), dim3(256), 0, s, x, y, B, H, W, C, OH, OW);
+    hipLaunchKernelGGL(subsample2_nhwc, dim3(blocks), dim3(256), 0, s, x, y, B, H, W, C, OH, OW, st);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
-int apse_k_nhwc_to_nchw(const float* x, float* y, int B, int HW, int C, hipStream_t s) {
-    hipLaunchKernelGGL(nhwc_to_nchw, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, x, y, B, HW, C);
+int apse_k_nhwc_to_nchw(const void* x, float* y, int B, int HW, int C, int st, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_nchw, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, x, y, B, HW, C, st);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 }

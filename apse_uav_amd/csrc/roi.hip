@@ -9,9 +9,10 @@
 #include <float.h>
 
 struct FpnMaps {
-    const float* p[4];     // p2..p5, each [B][H][W][256]
+    const void* p[4];      // p2..p5, each [B][H][W][256], f32 or 16-bit (st)
     int H[4], W[4];
     float scale[4];        // 1/4 .. 1/32
+    int st;                // storage type of the maps: 0 f32, 1 bf16, 2 f16
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -21,7 +22,7 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 __global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const float* __restrict__ rois,
                                                       const int* __restrict__ roi_img, const int* __restrict__ cnt,
                                                       const int* __restrict__ total, int per_img, int n_max, int R,
-                                                      float* __restrict__ out) {
+                                                      void* __restrict__ out, int out_st) {
     const int lane = threadIdx.x & 63;
     const int rr = R * R;
     const int nlive = roi_img ? (*total < n_max ? *total : n_max) : n_max;
@@ -38,9 +39,9 @@ __global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const flo
         img = r / per_img;
         live = (r - img * per_img) < cnt[img];
     }
-    float* o = out + ((size_t)r * rr + pb) * 256 + lane * 4;
+    const size_t o = ((size_t)r * rr + pb) * 256 + lane * 4;
     if (!live) {
-        if (!roi_img) *reinterpret_cast<f32x4*>(o) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!roi_img) apse_st4(out, o, f32x4{0.f, 0.f, 0.f, 0.f}, out_st);
         continue;                         // packed list: rows past the count are never read
     }
     const float x1 = rois[r * 4 + 0], y1 = rois[r * 4 + 1], x2 = rois[r * 4 + 2], y2 = rois[r * 4 + 3];
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const flo
     const int lv = (int)lvf - 2;
     const int H = F.H[lv], W = F.W[lv];
     const float sc = F.scale[lv];
-    const float* f = F.p[lv] + (size_t)img * H * W * 256 + lane * 4;
+    const void* fmap = F.p[lv];
+    const size_t f = (size_t)img * H * W * 256 + lane * 4;
     const float sw = x1 * sc - 0.5f, sh = y1 * sc - 0.5f;
     const float ew = x2 * sc - 0.5f, eh = y2 * sc - 0.5f;
     const float rw = ew - sw, rh = eh - sh;
@@ -74,19 +76,19 @@ __global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const flo
             if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
             const float lx = x - (float)xl, hx = 1.f - lx;
             const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-            const f32x4 v1 = ld4(f + ((size_t)yl * W + xl) * 256);
-            const f32x4 v2 = ld4(f + ((size_t)yl * W + xh) * 256);
-            const f32x4 v3 = ld4(f + ((size_t)yh * W + xl) * 256);
-            const f32x4 v4 = ld4(f + ((size_t)yh * W + xh) * 256);
+            const f32x4 v1 = apse_ld4(fmap, f + ((size_t)yl * W + xl) * 256, F.st);
+            const f32x4 v2 = apse_ld4(fmap, f + ((size_t)yl * W + xh) * 256, F.st);
+            const f32x4 v3 = apse_ld4(fmap, f + ((size_t)yh * W + xl) * 256, F.st);
+            const f32x4 v4 = apse_ld4(fmap, f + ((size_t)yh * W + xh) * 256, F.st);
             acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
         }
     }
-    *reinterpret_cast<f32x4*>(o) = acc / cntf;
+    apse_st4(out, o, acc / cntf, out_st);
     }
 }
 
 // torchvision roi_pool forward on one NHWC map; rois in original-frame pixels, packed list.
-__global__ __launch_bounds__(256) void roi_pool_nhwc(const float* __restrict__ feat, int H, int W,
+__global__ __launch_bounds__(256) void roi_pool_nhwc(const void* __restrict__ feat, int st, int H, int W,
                                                      const float* __restrict__ rois, const int* __restrict__ roi_img,
                                                      const int* __restrict__ total, int n_max, int R, float scale,
                                                      float* __restrict__ out) {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void roi_pool_nhwc(const float* __restrict__ f
     const int r = bin / rr;
     const int pb = bin - r * rr;
     const int ph = pb / R, pw = pb - ph * R;
-    const float* f = feat + (size_t)roi_img[r] * H * W * 256 + lane * 4;
+    const size_t f = (size_t)roi_img[r] * H * W * 256 + lane * 4;
     const int sw = (int)roundf(rois[r * 4 + 0] * scale), sh = (int)roundf(rois[r * 4 + 1] * scale);
     const int ew = (int)roundf(rois[r * 4 + 2] * scale), eh = (int)roundf(rois[r * 4 + 3] * scale);
     const int rw = (ew - sw + 1) > 1 ? (ew - sw + 1) : 1;
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void roi_pool_nhwc(const float* __restrict__ f
     f32x4 m = {init, init, init, init};
     for (int y = hs; y < he; ++y)
         for (int x = ws; x < we; ++x) {
-            const f32x4 v = ld4(f + ((size_t)y * W + x) * 256);
+            const f32x4 v = apse_ld4(feat, f + ((size_t)y * W + x) * 256, st);
             m[0] = v[0] > m[0] ? v[0] : m[0];
             m[1] = v[1] > m[1] ? v[1] : m[1];
             m[2] = v[2] > m[2] ? v[2] : m[2];
@@ -147,18 +149,18 @@ __global__ __launch_bounds__(64) void sqdist_matrix(const float* __restrict__ a,
 
 extern "C" {
 int apse_k_roi_align(const FpnMaps* F, const float* rois, const int* roi_img, const int* cnt, const int* total, int per_img,
-                     int n_max, int R, float* out, hipStream_t s) {
+                     int n_max, int R, void* out, int out_st, hipStream_t s) {
     int blocks = (n_max * R * R + 3) / 4;
     if (roi_img && blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(roi_align_nhwc, dim3(blocks), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R,
-                       out);
+                       out, out_st);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
-int apse_k_roi_pool(const float* feat, int H, int W, const float* rois, const int* roi_img, const int* total, int n_max,
+int apse_k_roi_pool(const void* feat, int st, int H, int W, const float* rois, const int* roi_img, const int* total, int n_max,
                     int R, float scale, float* out, hipStream_t s) {
     int blocks = (n_max * R * R + 3) / 4;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(roi_pool_nhwc, dim3(blocks), dim3(256), 0, s, feat, H, W, rois, roi_img, total, n_max, R, scale,
+    hipLaunchKernelGGL(roi_pool_nhwc, dim3(blocks), dim3(256), 0, s, feat, st, H, W, rois, roi_img, total, n_max, R, scale,
                        out);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }

@@ -171,6 +171,7 @@ class TrackRCNN:
         pw = (c.image_w + 31) // 32 * 32
         c.assoc_scale = (pw // 4) / float(c.frame_w)          # features.size()[3] / image_size[1]  (rcnn_tracker.py:165)
         c.compute_dtype = {"f32": 0, "bf16": 1, "f16": 2, "fp16": 2}[str(cfg.APSE.DTYPE)]
+        c.storage16 = int(bool(cfg.APSE.get("STORAGE16", True))) if c.compute_dtype else 0
         ctx = C.c_void_p()
         _lib.check(lib.apse_create(C.byref(c), C.byref(ctx)), None, "apse_create: " + lib.apse_last_error(None).decode())
         try:
@@ -252,7 +253,7 @@ class TrackRCNN:
     def debug_tensor(self, name, dtype=torch.float32):
         n = C.c_size_t()
         self._call("apse_debug_tensor", name.encode(), None, 0, C.byref(n), _lib.stream_ptr())
-        out = torch.empty(n.value // 4, dtype=dtype, device=self.device)
+        out = torch.empty(n.value // torch.empty((), dtype=dtype).element_size(), dtype=dtype, device=self.device)
         self._call("apse_debug_tensor", name.encode(), _lib.ptr(out), n.value, C.byref(n), _lib.stream_ptr())
         return out
 

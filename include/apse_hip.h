@@ -53,7 +53,9 @@ typedef struct apse_config {
     int embed_dim;                /* 128 */
     float assoc_scale;            /* roi_pool spatial scale = p2 width / frame width (rcnn_tracker.py:165) */
     int compute_dtype;            /* 0 = exact f32 MFMA everywhere (reference numerics); 1 = bf16, 2 = f16 matrix cores with
-                                     f32 accumulate and f32 storage for the trunk / head GEMMs (decision layers stay f32) */
+                                     f32 accumulate for the trunk / head GEMMs (decision layers stay f32) */
+    int storage16;                /* with compute_dtype 1/2: 1 = activations live in HBM in the 16-bit operand type (half
+                                     the traffic, no conversion on the way to the matrix cores); 0 = f32 storage */
 } apse_config;
 
 /* Byte offsets of the per-forward results block (one D2H copy, apse_read_results). n = max_batch*dets_per_image. */

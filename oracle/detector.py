@@ -34,6 +34,9 @@ DEFAULT_CFG = dict(
     # filters in f32, filters and layer inputs rounded to bf16 (nearest-even), f32 accumulation and f32
     # outputs; the narrow decision heads (RPN logits/deltas, box predictor, mask logits) stay f32.
     bf16=False,
+    # storage16=True (with bf16): every activation the bulk GEMMs produce is also ROUNDED to the 16-bit type
+    # where the product stores it (after bias / residual / ReLU), like cfg.APSE.STORAGE16.
+    storage16=False,
 )
 
 F32_LAYERS = ("proposal_generator.rpn_head.objectness_logits", "proposal_generator.rpn_head.anchor_deltas",
@@ -74,7 +77,11 @@ class DetectorOracle:
             _R16_DTYPE[0] = torch.bfloat16
 
     # ------------------------------------------------------------------ helpers
-    def _conv(self, x, name, stride=1, padding=0, relu=False):
+    def _st(self, t):
+        """Storage rounding of a tensor the product keeps in HBM as bf16 / f16."""
+        return _r16(t) if (self.cfg["bf16"] and self.cfg["storage16"]) else t
+
+    def _conv(self, x, name, stride=1, padding=0, relu=False, store=True):
         w = self.sd[name + ".weight"]
         b = self.sd.get(name + ".bias")
         if self.cfg["bf16"] and name not in F32_LAYERS:
@@ -84,7 +91,8 @@ class DetectorOracle:
                 b = self.sd[name + ".norm.bias"] - self.sd[name + ".norm.running_mean"] * scale
                 w = w * scale.view(-1, 1, 1, 1)
             y = F.conv2d(_r16(x), _r16(w), b, stride=stride, padding=padding)
-            return F.relu(y) if relu else y
+            y = F.relu(y) if relu else y
+            return self._st(y) if store else y
         y = F.conv2d(x, w, b, stride=stride, padding=padding)
         if (name + ".norm.weight") in self.sd:
             # FrozenBatchNorm2d: x * scale + bias with scale = w * rsqrt(var + eps)
@@ -118,12 +126,12 @@ class DetectorOracle:
     def bottleneck(self, x, prefix, stride):
         out = self._conv(x, prefix + ".conv1", stride=stride, relu=True)       # STRIDE_IN_1X1
         out = self._conv(out, prefix + ".conv2", stride=1, padding=1, relu=True)
-        out = self._conv(out, prefix + ".conv3")
+        out = self._conv(out, prefix + ".conv3", store=False)     # residual add + ReLU happen before the store
         if (prefix + ".shortcut.weight") in self.sd:
             sc = self._conv(x, prefix + ".shortcut", stride=stride)
         else:
             sc = x
-        return F.relu(out + sc)
+        return self._st(F.relu(out + sc))
 
     def bottom_up(self, x):
         feats = {}
@@ -144,8 +152,8 @@ class DetectorOracle:
         out["p5"] = self._conv(prev, "backbone.fpn_output5", padding=1)
         for lvl in (4, 3, 2):
             top = F.interpolate(prev, scale_factor=2, mode="nearest")
-            lat = self._conv(feats["res%d" % lvl], "backbone.fpn_lateral%d" % lvl)
-            prev = lat + top
+            lat = self._conv(feats["res%d" % lvl], "backbone.fpn_lateral%d" % lvl, store=False)
+            prev = self._st(lat + top)
             out["p%d" % lvl] = self._conv(prev, "backbone.fpn_output%d" % lvl, padding=1)
         out["p6"] = F.max_pool2d(out["p5"], kernel_size=1, stride=2, padding=0)
         return out
@@ -200,10 +208,11 @@ class DetectorOracle:
 
     def box_features(self, feats, proposals):
         pooled = ops.roi_pooler([feats[k][0] for k in ("p2", "p3", "p4", "p5")], proposals, self.cfg["box_pool"])
+        pooled = self._st(pooled)
         x = pooled.flatten(1)
         q = _r16 if self.cfg["bf16"] else (lambda t: t)
-        x = F.relu(F.linear(q(x), q(self.sd["roi_heads.box_head.fc1.weight"]), self.sd["roi_heads.box_head.fc1.bias"]))
-        x = F.relu(F.linear(q(x), q(self.sd["roi_heads.box_head.fc2.weight"]), self.sd["roi_heads.box_head.fc2.bias"]))
+        x = self._st(F.relu(F.linear(q(x), q(self.sd["roi_heads.box_head.fc1.weight"]), self.sd["roi_heads.box_head.fc1.bias"])))
+        x = self._st(F.relu(F.linear(q(x), q(self.sd["roi_heads.box_head.fc2.weight"]), self.sd["roi_heads.box_head.fc2.bias"])))
         cls = F.linear(x, self.sd["roi_heads.box_predictor.cls_score.weight"], self.sd["roi_heads.box_predictor.cls_score.bias"])
         reg = F.linear(x, self.sd["roi_heads.box_predictor.bbox_pred.weight"], self.sd["roi_heads.box_predictor.bbox_pred.bias"])
         return dict(pooled=pooled, cls_logits=cls, deltas=reg)
@@ -237,13 +246,13 @@ class DetectorOracle:
         if n == 0:
             return dict(pooled=torch.zeros((0, 256, m, m)), logits=torch.zeros((0, self.cfg["num_classes"], 2 * m, 2 * m)),
                         probs=torch.zeros((0, 2 * m, 2 * m)))
-        x = ops.roi_pooler([feats[k][0] for k in ("p2", "p3", "p4", "p5")], boxes, m)
+        x = self._st(ops.roi_pooler([feats[k][0] for k in ("p2", "p3", "p4", "p5")], boxes, m))
         pooled = x
         for i in range(1, 5):
             x = self._conv(x, "roi_heads.mask_head.mask_fcn%d" % i, padding=1, relu=True)
         q = _r16 if self.cfg["bf16"] else (lambda t: t)
-        x = F.relu(F.conv_transpose2d(q(x), q(self.sd["roi_heads.mask_head.deconv.weight"]),
-                                      self.sd["roi_heads.mask_head.deconv.bias"], stride=2))
+        x = self._st(F.relu(F.conv_transpose2d(q(x), q(self.sd["roi_heads.mask_head.deconv.weight"]),
+                                               self.sd["roi_heads.mask_head.deconv.bias"], stride=2)))
         logits = self._conv(x, "roi_heads.mask_head.predictor")
         probs = logits.sigmoid()[torch.arange(n), classes]
         return dict(pooled=pooled, logits=logits, probs=probs)

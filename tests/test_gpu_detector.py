@@ -142,8 +142,9 @@ def test_sequence_ids_and_csv(setup, logdir, tmp_path):
     assert same >= len(lines) - 1              # integer cells; a threshold-edge pixel may move one centroid by 1
 
 
+@pytest.mark.parametrize("storage", [True, False], ids=["store16", "store32"])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_bf16_mode_vs_bf16_oracle(setup, logdir, dtype):
+def test_bf16_mode_vs_bf16_oracle(setup, logdir, dtype, storage):
     """cfg.APSE.DTYPE = "bf16": bf16 matrix cores, f32 accumulate / storage.  Checked against the oracle run
     with the same quantisation points (filters and layer inputs rounded to bf16).  A different f32
     accumulation order can flip the bf16 rounding of a next-layer input (2^-9 relative), so the float
@@ -153,22 +154,23 @@ def test_bf16_mode_vs_bf16_oracle(setup, logdir, dtype):
     from oracle.detector import DetectorOracle
     cfg = _cfg()
     cfg.APSE.DTYPE = dtype
+    cfg.APSE.STORAGE16 = storage
     tr = RcnnTracker(cfg, FRAME, setup["asd"], detector_state=setup["sd"])
     frame = setup["seq"].frame(0)
     pred, feats = tr.predictor(frame)
     inst = pred["instances"]
     oracle = DetectorOracle(setup["sd"], dict(depth_blocks=BLOCKS, min_size=256, max_size=448,
-                                              bf16=("f16" if dtype == "f16" else True)))
+                                              bf16=("f16" if dtype == "f16" else True), storage16=storage))
     img = np.asarray(Image.fromarray(frame).resize((setup["iw"], setup["ih"]), Image.BILINEAR))
     post = oracle.inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), FRAME[0], FRAME[1])
     for k in ("p2", "p4", "p6"):
         got, ref = feats[k].cpu(), post["features"][k]
         d = float((got - ref).abs().max() / ref.abs().max())
         mean = float((got - ref).abs().mean() / ref.abs().mean())
-        _log(logdir, dtype + "/feat/" + k, dict(rel_max=d, rel_mean=mean))
+        _log(logdir, dtype + ("/s16" if storage else "/s32") + "/feat/" + k, dict(rel_max=d, rel_mean=mean))
         assert d < 3e-2 and mean < 1e-2        # bf16 noise floor: ~2^-9 after the roundings decorrelate
     n, rn = len(inst), int(post["boxes"].shape[0])
-    _log(logdir, dtype + "/dets", dict(n=n, ref_n=rn, scores=[round(float(s), 4) for s in inst.scores],
+    _log(logdir, dtype + ("/s16" if storage else "/s32") + "/dets", dict(n=n, ref_n=rn, scores=[round(float(s), 4) for s in inst.scores],
                                    ref=[round(float(s), 4) for s in post["scores"]]))
     assert abs(n - rn) <= 2
     matched = 0
@@ -177,7 +179,7 @@ def test_bf16_mode_vs_bf16_oracle(setup, logdir, dtype):
         d = (post["boxes"] - b).abs().max(dim=1).values if rn else torch.tensor([])
         if rn and float(d.min()) < 2.0:
             matched += 1
-    _log(logdir, dtype + "/matched", dict(matched=matched, n=n))
+    _log(logdir, dtype + ("/s16" if storage else "/s32") + "/matched", dict(matched=matched, n=n))
     assert matched >= min(n, rn) - 2
 
 
@@ -293,7 +295,7 @@ def test_config3_like_batch4_bf16_with_preproc(setup, logdir, golden_dir):
     tr.predictor.set_camera(cam_small)
     frames = [setup["seq"].frame(t) for t in range(4)]
     out = tr.predictor.predict_batch(frames, want_masks=False)[0]
-    oracle = DetectorOracle(setup["sd"], dict(depth_blocks=BLOCKS, min_size=256, max_size=448, bf16=True))
+    oracle = DetectorOracle(setup["sd"], dict(depth_blocks=BLOCKS, min_size=256, max_size=448, bf16=True, storage16=True))
     tot = matched = 0
     for b in range(4):
         pre = op.preprocess_img(frames[b], cam_small["mtx"], cam_small["dist"])

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "missing export " + name
     assert set(_lib.EXPORTS) <= declared
-    assert ctypes.sizeof(_lib.Config) == 26 * 4      # apse_config: 26 four-byte fields
+    assert ctypes.sizeof(_lib.Config) == 27 * 4      # apse_config: 27 four-byte fields
 
 
 def test_product_fails_loudly_without_gpu():
