@@ -84,6 +84,27 @@ __device__ __forceinline__ void apse_st4(void* base, size_t idx, f32x4 v, int st
         *reinterpret_cast<f16x4_t*>(reinterpret_cast<uint16_t*>(base) + idx) = h;
     }
 }
+// Warm the NEXT layer's filters from this launch: the next launch otherwise starts with every block missing on the
+// same cold lines (~1-2 us at batch 1, where a layer is only 15-60 us long).  Each block of the first K slice touches
+// one slice of at most 16 KB: four independent 16-byte loads per thread, ISSUED in front of the block's first
+// prologue fetch and RETIRED (a dummy use) behind it, so they share the prologue's one memory round trip.
+// Values are discarded.
+struct ApseWarm { f32x4 v[4]; };
+__device__ __forceinline__ void apse_warm_issue(ApseWarm& wv, const void* w, unsigned bytes, unsigned blk, unsigned nblk, int tid) {
+    const unsigned stride = (bytes / nblk + 1023u) & ~1023u;
+    const unsigned len = stride > 16384u ? 16384u : stride;
+    const unsigned lo = blk * stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned o = (unsigned)(i * 256 + tid) * 16u;
+        wv.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (w && o < len && lo + o + 16u <= bytes) wv.v[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(w) + lo + o);
+    }
+}
+__device__ __forceinline__ void apse_warm_retire(ApseWarm& wv) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wv.v[i]));
+}
 __device__ __forceinline__ void apse_st1(void* base, size_t idx, float v, int st) {
     if (st == 0) reinterpret_cast<float*>(base)[idx] = v;
     else if (st == 1) reinterpret_cast<__bf16*>(base)[idx] = (__bf16)v;

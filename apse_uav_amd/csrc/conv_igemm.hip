@@ -19,7 +19,12 @@
 // 1024 cycles/wave at 64x64 and 4096 at 128x128); one barrier per k-step.
 #include "apse_common.h"
 
-template <int WM, int WN, int TM, int TN, int KS>
+// XT = 0: x is f32 and is read through a buffer descriptor: a tap outside the image (or a k sub-step past the end)
+// gets an offset beyond the buffer, for which the hardware range check returns zeros -> the staging code has no
+// branches, the whole k-step is one basic block and the compiler spreads the address arithmetic and the loads over
+// the gaps of the MFMA stream.  XT = 1: x may be 16-bit (typed loads, conditional; only the small-Cout head layers
+// of the 16-bit modes take this instantiation).
+template <int WM, int WN, int TM, int TN, int KS, int XT>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -58,18 +63,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     const int ohw = p.OH * p.OW;
     const size_t w_row = (size_t)p.KH * p.KWCp;
     const bool direct = (p.splitk == 1);
+    __amdgpu_buffer_rsrc_t xrsrc;
+    if constexpr (XT == 0)
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)(((unsigned)(p.B * p.H * p.W) << p.cin_log2) * 4u), 0x00020000);
 
-    // Warm the next layer's filters: its launch starts with every block missing on the same cold lines
-    // (~1-2 us at batch 1, where a layer is only 15-60 us long).  Each block pulls a disjoint slice through
-    // its L2 while this layer's main loop runs; the values are discarded.
-    if (p.next_w && z == 0) {
-        const unsigned per_block = (p.next_w_bytes / gridDim.x + 1023u) & ~1023u;
-        const unsigned lo = blockIdx.x * per_block;
-        for (unsigned o = lo + tid * 16u; o < lo + per_block && o + 16u <= p.next_w_bytes; o += 256u * 16u) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.next_w) + o);
-            asm volatile("" ::"v"(v));
-        }
-    }
+    bool warm_pending = p.next_w && z == 0;     // the block's first tile also warms a slice of the next layer's filters
     // Persistent over tiles: the grid is min(tiles, cap); count-limited launches (packed detection
     // lists) therefore spend nothing on tiles past the device-side count.
     for (int wg = blockIdx.x; wg < nwg; wg += gridDim.x) {
@@ -84,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
         const int m0 = tile_m * BM, n0 = tile_n * BN;
 
         // per-thread staging rows
-        int a_iy0[AP], a_ix0[AP], a_pix[AP];
+        int a_iy0[AP], a_ix0[AP], a_pix[AP], a_base[AP];
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int m = m0 + srow + 32 * i;
@@ -101,10 +99,65 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
                 a_ix0[i] = 0;
                 a_pix[i] = 0;
             }
+            a_base[i] = (a_pix[i] + a_iy0[i] * p.W + a_ix0[i]) << p.cin_log2;   // element offset of tap (r = 0, q = 0); only used when valid
         }
 
         f32x4 ra[KS][AP], rb[KS][BP];
+        // (filter row, 32-float step inside the row) of the next k sub-step to fetch, advanced incrementally
+        int ld_r, ld_q;
+        {
+            const int ss0 = s_begin * KS;
+            ld_r = ss0 / steps_per_row;
+            ld_q = ss0 - ld_r * steps_per_row;
+        }
+        const float* wrow[BP];
+#pragma unroll
+        for (int i = 0; i < BP; ++i) wrow[i] = p.w + (size_t)(n0 + srow + 32 * i) * w_row + (slot << 2);
+        // One "piece" = one 16-byte fetch of this thread (pieces 0..AP-1: A rows, AP..AP+BP-1: B rows of sub-step u).
+        // The k-step issues its pieces one per MFMA group, pinned there with sched_barriers, so the address
+        // arithmetic and the fetches ride in the gaps of the matrix pipe instead of in front of it.
+        int cur_r = 0, cur_ry = 0, cur_q = 0, cur_rowoff = 0, cur_woff = 0, cur_dpx = 0;
+        auto fetch_piece = [&](int u, int j) {
+            if (j == 0) {                      // scalars of sub-step u
+                const bool live = ld_r < p.KH;
+                cur_r = live ? ld_r : p.KH - 1;
+                cur_ry = live ? ld_r : (1 << 28);
+                cur_q = (ld_q << 5) + (slot << 2);
+                cur_dpx = cur_q >> p.cin_log2;
+                cur_rowoff = ((cur_r * p.W) << p.cin_log2) + cur_q;
+                cur_woff = cur_r * p.KWCp + (ld_q << 5);
+                ++ld_q;
+                if (ld_q == steps_per_row) { ld_q = 0; ++ld_r; }
+            }
+            if (j < AP) {
+                const int iy = a_iy0[j] + cur_ry;            // cur_ry is far out of range on a dead sub-step
+                const int px = a_ix0[j] + cur_dpx;
+                const int okm = -(int)(((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)p.W));   // all ones when the tap is inside
+                const unsigned off = (((unsigned)(a_base[j] + cur_rowoff) << 2) & (unsigned)okm) | (0xfffffff0u & ~(unsigned)okm);
+                ra[u][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+            } else {
+                rb[u][j - AP] = *reinterpret_cast<const f32x4*>(wrow[j - AP] + cur_woff);
+            }
+        };
+        auto store_piece = [&](int buf, int u, int j) {
+            if (j < AP) {
+                const int row = srow + 32 * j;
+                const int ps = slot ^ ((row >> 1) & 7);
+                *reinterpret_cast<f32x4*>(As + (buf * KS + u) * BM * 32 + row * 32 + ps * 4) = ra[u][j];
+            } else {
+                const int row = srow + 32 * (j - AP);
+                const int ps = slot ^ ((row >> 1) & 7);
+                *reinterpret_cast<f32x4*>(Bs + (buf * KS + u) * BN * 32 + row * 32 + ps * 4) = rb[u][j - AP];
+            }
+        };
+        auto load_step_bl = [&]() {
+#pragma unroll
+            for (int u = 0; u < KS; ++u)
+#pragma unroll
+                for (int j = 0; j < AP + BP; ++j) fetch_piece(u, j);
+        };
         auto load_step = [&](int sb) {
+            if constexpr (XT == 0) { load_step_bl(); return; }
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
                 int ss = sb * KS + u;
@@ -158,12 +211,71 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
                 for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
         if (s_begin < s_end) {
+            ApseWarm warm;
+            const bool warm_now = warm_pending;
+            warm_pending = false;
+            if (warm_now) apse_warm_issue(warm, p.next_w, p.next_w_bytes, blockIdx.x, gridDim.x, tid);
             load_step(s_begin);
             store_step(0);
+            if (warm_now) apse_warm_retire(warm);
             __syncthreads();
+            if constexpr (XT == 0) {
+                constexpr int NP = KS * (AP + BP);          // fetch pieces per k-step
+                constexpr int G = 16 * KS;                  // MFMA groups per k-step (TM*TN MFMAs each)
+                constexpr int SP = (G / 2) / NP > 0 ? (G / 2) / NP : 1;
+                static_assert(NP * SP <= G / 2 + SP - 1 && G / 2 + (NP - 1) * SP < G, "piece schedule does not fit the k-step");
+                for (int sb = s_begin; sb < s_end; ++sb) {
+                    const int buf = (sb - s_begin) & 1;
+                    f32x4 af[2][TM], bf[2][TN];
+                    auto load_frags = [&](int cc, int fb) {
+                        const int u = cc >> 2, c = cc & 3;
+                        const float* Ab = As + (buf * KS + u) * BM * 32;
+                        const float* Bb = Bs + (buf * KS + u) * BN * 32;
+                        const int ls = 2 * c + fh;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const int row = (wm * TM + i) * 32 + fr;
+                            af[fb][i] = *reinterpret_cast<const f32x4*>(Ab + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
+                        }
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const int row = (wn * TN + j) * 32 + fr;
+                            bf[fb][j] = *reinterpret_cast<const f32x4*>(Bb + row * 32 + ((ls ^ ((row >> 1) & 7)) << 2));
+                        }
+                    };
+                    load_frags(0, 0);
+#pragma unroll
+                    for (int cc = 0; cc < 4 * KS; ++cc) {
+                        if (cc + 1 < 4 * KS) load_frags(cc + 1, (cc + 1) & 1);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int g = cc * 4 + k;
+                            // first half of the step: fetch piece g/SP of step sb+1 (unconditional: a dead step past the end
+                            // reads zeros / the next K slice and is never consumed); second half: hand it to LDS buf^1
+                            if (g % SP == 0 && g / SP < NP) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                fetch_piece((g / SP) / (AP + BP), (g / SP) % (AP + BP));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            if (g >= G / 2 && (g - G / 2) % SP == 0 && (g - G / 2) / SP < NP) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                store_piece(buf ^ 1, ((g - G / 2) / SP) / (AP + BP), ((g - G / 2) / SP) % (AP + BP));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cc & 1][i][k], bf[cc & 1][j][k], acc[i][j], 0, 0, 0);
+                        }
+                    }
+                    __syncthreads();
+                }
+            } else
             for (int sb = s_begin; sb < s_end; ++sb) {
                 const int buf = (sb - s_begin) & 1;
-                if (sb + 1 < s_end) load_step(sb + 1);
+                const bool more = sb + 1 < s_end;
+                if (more) load_step(sb + 1);
                 // fragments are double-buffered in registers: the ds_read_b128s of chunk c+1 are issued
                 // before the MFMAs of chunk c, so LDS latency hides behind the matrix pipe.
                 f32x4 af[2][TM], bf[2][TN];
@@ -190,7 +302,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
                     // the next step's tile goes to LDS in the middle of this step's MFMA stream (its global
                     // loads were issued at the top of the step): the ds_writes issue under the matrix pipe
                     // instead of in front of the barrier.  buf^1 was last read in the previous step.
-                    if (cc == STORE_AT && sb + 1 < s_end) store_step(buf ^ 1);
+                    if (cc == STORE_AT && more) store_step(buf ^ 1);
 #ifdef APSE_SETPRIO
                     __builtin_amdgcn_s_setprio(1);
 #endif
@@ -372,21 +484,21 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvParams p) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, int KS>
-static int launch_cfg(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+template <int WM, int WN, int TM, int TN, int KS, int XT>
+static int launch_cfg_x(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
     const size_t lds_stage = (size_t)2 * KS * (BM + BN) * 32 * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float) + 16;
     const size_t lds = lds_stage > lds_c ? lds_stage : lds_c;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, KS>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, KS, XT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     const int grid_x = (p.m_count && tiles > 1024) ? 1024 : tiles;
     if (ev0) hipEventRecord(ev0, s);
-    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, KS>), dim3(grid_x, p.splitk), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, KS, XT>), dim3(grid_x, p.splitk), dim3(256), lds, s, p);
     if (ev1) hipEventRecord(ev1, s);
     if (p.splitk > 1 && !p.tile_cnt) {
         const size_t total = (size_t)p.M * p.Cout;
@@ -395,6 +507,13 @@ static int launch_cfg(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEve
         hipLaunchKernelGGL(conv_splitk_reduce, dim3(blocks), dim3(256), 0, s, p);
     }
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+
+template <int WM, int WN, int TM, int TN, int KS>
+static int launch_cfg(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    // the descriptor path needs f32 activations of < 4 GiB (byte offsets are 32-bit)
+    const bool bl = p.x_st == 0 && (((size_t)p.B * p.H * p.W) << p.cin_log2) * 4 < 0xfffffff0ull;
+    return bl ? launch_cfg_x<WM, WN, TM, TN, KS, 0>(p, s, ev0, ev1) : launch_cfg_x<WM, WN, TM, TN, KS, 1>(p, s, ev0, ev1);
 }
 
 int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {

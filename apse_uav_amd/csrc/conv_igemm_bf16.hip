@@ -57,17 +57,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
     const size_t w_row = (size_t)p.KH * p.KWCp;
     const bool direct = (p.splitk == 1);
 
-    // Warm the next layer's filters: its launch starts with every block missing on the same cold lines
-    // (~1-2 us at batch 1, where a layer is only 15-60 us long).  Each block pulls a disjoint slice through
-    // its L2 while this layer's main loop runs; the values are discarded.
-    if (p.next_w && z == 0) {
-        const unsigned per_block = (p.next_w_bytes / gridDim.x + 1023u) & ~1023u;
-        const unsigned lo = blockIdx.x * per_block;
-        for (unsigned o = lo + tid * 16u; o < lo + per_block && o + 16u <= p.next_w_bytes; o += 256u * 16u) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.next_w) + o);
-            asm volatile("" ::"v"(v));
-        }
-    }
+    bool warm_pending = p.next_w && z == 0;     // the block's first tile also warms a slice of the next layer's filters
     // Persistent over tiles: the grid is min(tiles, cap); count-limited launches (packed detection
     // lists) therefore spend nothing on tiles past the device-side count.
     for (int wg = blockIdx.x; wg < nwg; wg += gridDim.x) {
@@ -188,8 +178,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvParams p) {
                 for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
         if (s_begin < s_end) {
+            ApseWarm warm;
+            const bool warm_now = warm_pending;
+            warm_pending = false;
+            if (warm_now) apse_warm_issue(warm, p.next_w, p.next_w_bytes, blockIdx.x, gridDim.x, tid);
             load_step(s_begin);
             store_step(0);
+            if (warm_now) apse_warm_retire(warm);
             __syncthreads();
             for (int sb = s_begin; sb < s_end; ++sb) {
                 const int buf = (sb - s_begin) & 1;
