@@ -29,6 +29,7 @@ struct ConvParams {
     int* tile_cnt;        // per-tile arrival counters (zero between launches) -> in-launch split-K reduction; nullptr -> reduce kernel
     const int* m_count;   // optional device int: number of valid items; M_eff = min(M, *m_count * m_per_item)
     int m_per_item;
+    int m_hint;           // expected live rows of a count-limited launch (sizes its grid; any count is still handled), 0 = none
     int B, H, W, cin_log2;
     int OH, OW, Cout;
     int KH, KW, stride, pad;

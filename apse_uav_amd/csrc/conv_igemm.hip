@@ -24,23 +24,30 @@
 // branches, the whole k-step is one basic block and the compiler spreads the address arithmetic and the loads over
 // the gaps of the MFMA stream.  XT = 1: x may be 16-bit (typed loads, conditional; only the small-Cout head layers
 // of the 16-bit modes take this instantiation).
-template <int WM, int WN, int TM, int TN, int KS, int XT>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
+// WK = 2: the block has 8 waves; wave group kg = wave / 4 owns the k sub-steps u with u % WK == kg of every step and
+// the groups' partial tiles are added (fixed order) in the epilogue.  For layers with about one tile per CU
+// (res4 at batch 1) this puts two waves on every SIMD without a second pass over a split-K workspace.
+template <int WM, int WN, int TM, int TN, int KS, int XT, int WK>
+__global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
+    constexpr int NT = 256 * WK;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int AP = BM / 32;   // staging passes (32 rows x 8 slots of 16 B per pass)
-    constexpr int BP = BN / 32;
+    constexpr int AP = BM / (32 * WK);   // staging passes (32*WK rows x 8 slots of 16 B per pass)
+    constexpr int BP = BN / (32 * WK);
+    constexpr int SR = 32 * WK;          // rows staged per pass
+    static_assert(AP >= 1 && BP >= 1 && KS % WK == 0 && (XT == 0 || WK == 1), "unsupported shape");
     constexpr int LDC = BN + 4;
     constexpr int STORE_AT = 4 * KS - 2;          // chunk before which the next k-slice is written to LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);   // [2][KS][BM*32]
     float* Bs = As + 2 * KS * BM * 32;            // [2][KS][BN*32]
-    float* Cs = reinterpret_cast<float*>(smem);   // epilogue view [BM][LDC]
+    float* Cs = reinterpret_cast<float*>(smem);   // epilogue view [WK][BM][LDC]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int kg = wave / (WM * WN);               // k group of this wave (0 when WK = 1)
+    const int wm = (wave % (WM * WN)) / WN, wn = wave % WN;
     const int fr = lane & 31, fh = lane >> 5;
     const int srow = tid >> 3, slot = tid & 7;
 
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
         int a_iy0[AP], a_ix0[AP], a_pix[AP], a_base[AP];
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            const int m = m0 + srow + 32 * i;
+            const int m = m0 + srow + SR * i;
             if (m < M) {
                 const int b = m / ohw;
                 const int rem = m - b * ohw;
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
         }
         const float* wrow[BP];
 #pragma unroll
-        for (int i = 0; i < BP; ++i) wrow[i] = p.w + (size_t)(n0 + srow + 32 * i) * w_row + (slot << 2);
+        for (int i = 0; i < BP; ++i) wrow[i] = p.w + (size_t)(n0 + srow + SR * i) * w_row + (slot << 2);
         // One "piece" = one 16-byte fetch of this thread (pieces 0..AP-1: A rows, AP..AP+BP-1: B rows of sub-step u).
         // The k-step issues its pieces one per MFMA group, pinned there with sched_barriers, so the address
         // arithmetic and the fetches ride in the gaps of the matrix pipe instead of in front of it.
@@ -141,11 +148,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
         };
         auto store_piece = [&](int buf, int u, int j) {
             if (j < AP) {
-                const int row = srow + 32 * j;
+                const int row = srow + SR * j;
                 const int ps = slot ^ ((row >> 1) & 7);
                 *reinterpret_cast<f32x4*>(As + (buf * KS + u) * BM * 32 + row * 32 + ps * 4) = ra[u][j];
             } else {
-                const int row = srow + 32 * (j - AP);
+                const int row = srow + SR * (j - AP);
                 const int ps = slot ^ ((row >> 1) & 7);
                 *reinterpret_cast<f32x4*>(Bs + (buf * KS + u) * BN * 32 + row * 32 + ps * 4) = rb[u][j - AP];
             }
@@ -221,14 +228,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
             __syncthreads();
             if constexpr (XT == 0) {
                 constexpr int NP = KS * (AP + BP);          // fetch pieces per k-step
-                constexpr int G = 16 * KS;                  // MFMA groups per k-step (TM*TN MFMAs each)
+                constexpr int G = 16 * KS / WK;             // MFMA groups per k-step and wave (TM*TN MFMAs each)
                 constexpr int SP = (G / 2) / NP > 0 ? (G / 2) / NP : 1;
                 static_assert(NP * SP <= G / 2 + SP - 1 && G / 2 + (NP - 1) * SP < G, "piece schedule does not fit the k-step");
                 for (int sb = s_begin; sb < s_end; ++sb) {
                     const int buf = (sb - s_begin) & 1;
                     f32x4 af[2][TM], bf[2][TN];
                     auto load_frags = [&](int cc, int fb) {
-                        const int u = cc >> 2, c = cc & 3;
+                        const int u = (cc >> 2) * WK + kg, c = cc & 3;      // this wave group's sub-steps only
                         const float* Ab = As + (buf * KS + u) * BM * 32;
                         const float* Bb = Bs + (buf * KS + u) * BN * 32;
                         const int ls = 2 * c + fh;
@@ -245,8 +252,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
                     };
                     load_frags(0, 0);
 #pragma unroll
-                    for (int cc = 0; cc < 4 * KS; ++cc) {
-                        if (cc + 1 < 4 * KS) load_frags(cc + 1, (cc + 1) & 1);
+                    for (int cc = 0; cc < 4 * KS / WK; ++cc) {
+                        if (cc + 1 < 4 * KS / WK) load_frags(cc + 1, (cc + 1) & 1);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int g = cc * 4 + k;
@@ -325,6 +332,40 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
         // Accumulators -> LDS (C layout, padded rows) -> 16-byte vector stores: one thread handles whole
         // float4 chunks of a row, so bias / residual / output move as dwordx4 and the per-element address
         // arithmetic of the 32x32 C/D map (col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)) disappears.
+        constexpr int C4 = BN / 4;                 // float4 chunks per tile row
+        constexpr int RPP = NT / C4;               // rows covered per pass
+        constexpr int PASSES = BM / RPP;
+        constexpr int RG = PASSES < 8 ? PASSES : 8;   // residual rows fetched together (independent loads, one wait)
+        const int c4 = tid % C4;
+        const int n = n0 + c4 * 4;
+        const int r0 = tid / C4;
+        // residual operand of output row m (zeros when the layer has none)
+        auto res_load = [&](int m) -> f32x4 {
+            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+            if (p.out_mode == 0 && m < M && n < p.Cout) {
+                if (p.res_mode == 1) {
+                    rv = apse_ld4(p.res, (size_t)m * p.Cout + n, p.res_st);
+                } else if (p.res_mode == 2) {
+                    const int b = m / ohw;
+                    const int rem = m - b * ohw;
+                    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                    const int hw2 = (p.OH >> 1) * (p.OW >> 1);
+                    rv = apse_ld4(p.res, ((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n, p.res_st);
+                }
+            }
+            return rv;
+        };
+        // the first group of residual rows is requested BEFORE the accumulators go through LDS: its HBM / MALL round
+        // trip (the skip tensor was written two or three layers ago) overlaps the C-tile shuffle and the barrier
+        f32x4 rgrp[RG];
+        const bool want_res = direct && p.res_mode != 0;
+        if (want_res) {
+#pragma unroll
+            for (int i = 0; i < RG; ++i) rgrp[i] = res_load(m0 + r0 + i * RPP);
+        } else {
+#pragma unroll
+            for (int i = 0; i < RG; ++i) rgrp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -332,13 +373,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int row = (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * fh;
-                    Cs[row * LDC + (wn * TN + j) * 32 + fr] = acc[i][j][v];
+                    Cs[(kg * BM + row) * LDC + (wn * TN + j) * 32 + fr] = acc[i][j][v];
                 }
         __syncthreads();
-        constexpr int C4 = BN / 4;                 // float4 chunks per tile row
-        constexpr int RPP = 256 / C4;              // rows covered per pass
-        const int c4 = tid % C4;
-        const int n = n0 + c4 * 4;
         bool vec_direct;
         if (p.out_mode == 1) vec_direct = (p.cdec & 3) == 0;
         else vec_direct = ((p.y_ld & 3) == 0) && ((p.y_coff & 3) == 0) && (p.y_coff + n + 4 <= p.y_ld);
@@ -349,20 +386,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
             if (p.out_mode == 1) { g = n / p.cdec; co = n - g * p.cdec; }
             if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);     // bias is padded to Cout_p
         }
+        // C tile value: the k groups' partial tiles are added in the fixed order kg = 0, 1, ...
+        auto ctile = [&](int r) -> f32x4 {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * LDC + c4 * 4);
+#pragma unroll
+            for (int k2 = 1; k2 < WK; ++k2) v += *reinterpret_cast<const f32x4*>(Cs + (k2 * BM + r) * LDC + c4 * 4);
+            return v;
+        };
         // bias + residual + ReLU + store of one float4 of output row m (the fused epilogue proper)
-        auto finish = [&](f32x4 val, int m) {
+        auto finish = [&](f32x4 val, int m, f32x4 resv) {
             val += bias4;
             size_t dst;                 // element index into y
             if (p.out_mode == 0) {
-                if (p.res_mode == 1) {
-                    val += apse_ld4(p.res, (size_t)m * p.Cout + n, p.res_st);
-                } else if (p.res_mode == 2) {
-                    const int b = m / ohw;
-                    const int rem = m - b * ohw;
-                    const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                    const int hw2 = (p.OH >> 1) * (p.OW >> 1);
-                    val += apse_ld4(p.res, ((size_t)b * hw2 + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * p.Cout + n, p.res_st);
-                }
+                val += resv;
                 dst = (size_t)m * p.y_ld + p.y_coff + n;
             } else {
                 const int b = m / ohw;
@@ -381,19 +417,28 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
             }
         };
         if (direct) {
-            if (n < p.Cout)
-                for (int r = tid / C4; r < BM; r += RPP) {
-                    const int m = m0 + r;
-                    if (m >= M) break;
-                    finish(*reinterpret_cast<const f32x4*>(Cs + r * LDC + c4 * 4), m);
+            if (n < p.Cout) {
+#pragma unroll
+                for (int g0 = 0; g0 < PASSES; g0 += RG) {
+                    if (g0 > 0 && want_res) {
+#pragma unroll
+                        for (int i = 0; i < RG; ++i) rgrp[i] = res_load(m0 + r0 + (g0 + i) * RPP);
+                    }
+#pragma unroll
+                    for (int i = 0; i < RG; ++i) {
+                        const int r = r0 + (g0 + i) * RPP;
+                        const int m = m0 + r;
+                        if (m < M) finish(ctile(r), m, rgrp[i]);
+                    }
                 }
+            }
         } else {
             // split-K: this block's partial tile goes to its slab of the workspace
             if (n < p.Cout)
                 for (int r = tid / C4; r < BM; r += RPP) {
                     const int m = m0 + r;
                     if (m >= M) break;
-                    const f32x4 val = *reinterpret_cast<const f32x4*>(Cs + r * LDC + c4 * 4);
+                    const f32x4 val = ctile(r);
                     float* dst = p.ws + ((size_t)z * p.M + m) * p.Cout + n;
                     if (vec_ws) *reinterpret_cast<f32x4*>(dst) = val;
                     else for (int k = 0; k < 4; ++k) if (n + k < p.Cout) dst[k] = val[k];
@@ -403,7 +448,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
                 // "In-launch split-K reduction"): plain slab stores -> every wave drains its stores -> barrier ->
                 // one lane: agent-scope release, arrival ticket; the block that draws splitk-1 acquires and sums
                 // the slabs in the fixed order z = 0..splitk-1 (bitwise reproducible, independent of arrival order).
-                int* flag = reinterpret_cast<int*>(Cs + BM * LDC);
+                int* flag = reinterpret_cast<int*>(Cs + WK * BM * LDC);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid == 0) {
@@ -429,7 +474,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
                             if (vec_ws) val += *reinterpret_cast<const f32x4*>(src + (size_t)zz * p.M * p.Cout);
                             else for (int k = 0; k < 4; ++k) if (n + k < p.Cout) val[k] += src[(size_t)zz * p.M * p.Cout + k];
                         }
-                        finish(val, m);
+                        finish(val, m, res_load(m));
                     }
                 }
             }
@@ -484,21 +529,32 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvParams p) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, int KS, int XT>
+template <int WM, int WN, int TM, int TN, int KS, int XT, int WK = 1>
 static int launch_cfg_x(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
-    const size_t lds_stage = (size_t)2 * KS * (BM + BN) * 32 * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float) + 16;
+    const size_t lds_stage = (size_t)2 * KS * (BM + BN) * 32 * sizeof(float), lds_c = (size_t)WK * BM * (BN + 4) * sizeof(float) + 16;
     const size_t lds = lds_stage > lds_c ? lds_stage : lds_c;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, KS, XT>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, KS, XT, WK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    const int grid_x = (p.m_count && tiles > 1024) ? 1024 : tiles;
+    // count-limited launches are persistent over the live tiles: size the grid for about twice the expected
+    // count (dead blocks still cost their launch), never above 1024 blocks
+    int grid_x = tiles;
+    if (p.m_count) {
+        int want = 1024;
+        if (p.m_hint > 0) {
+            want = 2 * ((p.m_hint + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+            if (want < 64) want = 64;
+            if (want > 1024) want = 1024;
+        }
+        if (grid_x > want) grid_x = want;
+    }
     if (ev0) hipEventRecord(ev0, s);
-    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, KS, XT>), dim3(grid_x, p.splitk), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, KS, XT, WK>), dim3(grid_x, p.splitk), dim3(256 * WK), lds, s, p);
     if (ev1) hipEventRecord(ev1, s);
     if (p.splitk > 1 && !p.tile_cnt) {
         const size_t total = (size_t)p.M * p.Cout;
@@ -509,11 +565,17 @@ static int launch_cfg_x(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipE
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 
+// the descriptor path needs f32 activations of < 4 GiB (byte offsets are 32-bit)
+static bool descriptor_ok(const ConvParams& p) { return p.x_st == 0 && (((size_t)p.B * p.H * p.W) << p.cin_log2) * 4 < 0xfffffff0ull; }
+
 template <int WM, int WN, int TM, int TN, int KS>
 static int launch_cfg(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    // the descriptor path needs f32 activations of < 4 GiB (byte offsets are 32-bit)
-    const bool bl = p.x_st == 0 && (((size_t)p.B * p.H * p.W) << p.cin_log2) * 4 < 0xfffffff0ull;
-    return bl ? launch_cfg_x<WM, WN, TM, TN, KS, 0>(p, s, ev0, ev1) : launch_cfg_x<WM, WN, TM, TN, KS, 1>(p, s, ev0, ev1);
+    return descriptor_ok(p) ? launch_cfg_x<WM, WN, TM, TN, KS, 0>(p, s, ev0, ev1) : launch_cfg_x<WM, WN, TM, TN, KS, 1>(p, s, ev0, ev1);
+}
+// 8-wave shapes exist for the descriptor path only; anything else falls back to the 4-wave shape of the same tile
+template <int WM, int WN, int TM, int TN, int KS, int KSF>
+static int launch_cfg_k2(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    return descriptor_ok(p) ? launch_cfg_x<WM, WN, TM, TN, KS, 0, 2>(p, s, ev0, ev1) : launch_cfg_x<WM, WN, TM, TN, KSF, 1>(p, s, ev0, ev1);
 }
 
 int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
@@ -536,14 +598,19 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0
         case 1: return launch_cfg<2, 2, 1, 1, 2>(p, s, ev0, ev1);
         case 2: return launch_cfg<4, 1, 1, 1, 2>(p, s, ev0, ev1);
         case 3: return launch_cfg<4, 1, 1, 2, 1>(p, s, ev0, ev1);
+        case 4: return launch_cfg<2, 2, 1, 1, 1>(p, s, ev0, ev1);     // 64x64, 32-deep steps: 32 KB of LDS, up to 4-5 blocks per CU
+        case 5: return launch_cfg<4, 1, 1, 1, 1>(p, s, ev0, ev1);     // 128x32, 32-deep steps
+        case 6: return launch_cfg_k2<2, 2, 1, 1, 2, 2>(p, s, ev0, ev1);  // 64x64, 8 waves: two k groups, 64-deep steps
+        case 7: return launch_cfg_k2<2, 2, 1, 1, 4, 2>(p, s, ev0, ev1);  // 64x64, 8 waves, 128-deep steps
         default: return APSE_E_INVALID;
     }
 }
 
 // Tile/split heuristic (tools/conv_sweep.py on MI355X): fill >= ~2 resident blocks per CU; prefer the
 // largest tile that does; for small-M layers trade tile size against split-K:
-//   large K   -> 128x128 tiles with the K range split across blocks (fc1, res4/res5 3x3),
-//   medium K  -> 64x64 tiles (unsplit once there are >= 192 of them),
+//   very large K -> 128x128 tiles with the K range split across blocks (fc1, res5 3x3),
+//   medium K  -> 64x64 tiles (unsplit once there are >= 192 of them: res4 3x3 / 1x1); with about one tile per CU
+//                the 8-wave two-k-group shape (cfg 7), which puts two waves on each SIMD,
 //   tiny K, wide N (res4 conv3) -> 128x64 tiles.
 int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk) {
     *splitk = 1;
@@ -561,11 +628,20 @@ int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk) {
         if (t128 < 384 && steps <= 16 && tiles(128, 64) >= 384) return 3;
         return 0;
     }
-    if (t128 >= 32 && steps >= 64) {
+    if (t128 >= 32 && steps >= 128) {
         *splitk = split_for(t128, 8);
         return 0;
     }
     const int t64 = tiles(64, 64);
-    if (t64 < 192 && steps >= 16) *splitk = split_for(t64, 4);
+    if (t64 >= 192) return t64 <= 320 ? 7 : 1;     // about one 64x64 tile per CU: the 8-wave shape keeps two waves on every SIMD
+    if (steps >= 16) {
+        // 8-wave blocks, K split so that there is about one block per CU (each split keeps >= 8 steps)
+        int sk = (256 + t64 / 2) / t64;
+        if (t64 > 64 && sk > 2) sk = 2;            // 65..191 tiles: two slices measured best (mask head, res5 1x1)
+        if (sk > steps / 8) sk = steps / 8;
+        if (sk > 64) sk = 64;
+        *splitk = sk < 1 ? 1 : sk;
+        return 7;
+    }
     return 1;
 }

@@ -353,7 +353,18 @@ static int launch_bf16(const ConvParams& p, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    const int grid_x = (p.m_count && tiles > 1024) ? 1024 : tiles;
+    // count-limited launches are persistent over the live tiles: size the grid for about twice the expected
+    // count (dead blocks still cost their launch), never above 1024 blocks
+    int grid_x = tiles;
+    if (p.m_count) {
+        int want = 1024;
+        if (p.m_hint > 0) {
+            want = 2 * ((p.m_hint + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+            if (want < 64) want = 64;
+            if (want > 1024) want = 1024;
+        }
+        if (grid_x > want) grid_x = want;
+    }
     hipLaunchKernelGGL((conv_igemm_bf16<ET, WM, WN, TM, TN, KS>), dim3(grid_x, p.splitk), dim3(256), lds, s, p);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
@@ -366,6 +377,9 @@ static int launch_et(const ConvParams& p, int cfg, hipStream_t s) {
         case 1: return launch_bf16<ET, 2, 2, 1, 1, 2>(p, s);
         case 2: return launch_bf16<ET, 4, 1, 1, 1, 2>(p, s);
         case 3: return launch_bf16<ET, 4, 1, 1, 2, 1>(p, s);
+        case 4: return launch_bf16<ET, 2, 2, 1, 1, 2>(p, s);      // the f32 kernel's extra shapes map to their nearest 16-bit one
+        case 5: return launch_bf16<ET, 4, 1, 1, 1, 2>(p, s);
+        case 6: case 7: return launch_bf16<ET, 2, 2, 1, 1, 2>(p, s);
         default: return APSE_E_INVALID;
     }
 }

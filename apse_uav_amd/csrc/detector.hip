@@ -343,7 +343,7 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
             // (f32 132 -> 111 FPS): 64-512 KB of slabs per tile and an agent-scope release (L2 write-back) per
             // block; it stays available through apse_conv_desc.fuse_reduce for small slabs.
             p.tile_cnt = nullptr;
-            p.m_count = nullptr; p.m_per_item = p.OH * p.OW;
+            p.m_count = nullptr; p.m_per_item = p.OH * p.OW; p.m_hint = 0;
             int cfg = st.c.cfg;
             if (st.c.count_kind == 2) {
                 p.m_count = total_dev;
@@ -351,6 +351,7 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
                 const int mh = (c->hint_total > 0 ? c->hint_total : 1) * p.m_per_item;
                 int sk = 1;
                 cfg = apse_conv_pick_cfg(mh < p.M ? mh : p.M, p.Cout, p.steps_total, &sk);
+                p.m_hint = mh < p.M ? mh : p.M;
                 const size_t cap = c->ws_floats / ((size_t)p.M * p.Cout);
                 if ((size_t)sk > cap) sk = (int)cap;
                 p.splitk = sk < 1 ? 1 : sk;

@@ -25,7 +25,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CFG_NAMES = ["conv_igemm<128x128>", "conv_igemm<64x64>", "conv_igemm<128x32>", "conv_igemm<128x64>"]
+CFG_NAMES = ["conv_igemm<128x128>", "conv_igemm<64x64>", "conv_igemm<128x32>", "conv_igemm<128x64>",
+             "conv_igemm<64x64,k32>", "conv_igemm<128x32,k32>", "conv_igemm<64x64,8 waves,k64>", "conv_igemm<64x64,8 waves,k128>"]
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 dense
 
@@ -248,7 +249,7 @@ def main():
                          "traffic": None, "avg_launch_ms": round(ms / max(nl, 1), 5), "launches": int(nl),
                          "all_kernels": {CFG_NAMES[k]: {"ms": round(float(prof[k, 0]), 3),
                                                         "tflops": round(float(prof[k, 1] / max(prof[k, 0], 1e-9) / 1e9), 3),
-                                                        "launches": int(prof[k, 2])} for k in range(4)},
+                                                        "launches": int(prof[k, 2])} for k in range(8) if prof[k, 2] > 0},
                          "conv_ms_per_frame": round(total_conv_ms / max(n_instr * B, 1), 3), "instrumented_steps": n_instr,
                          "whole_path_tflops": round(flops_frame * fps / world / 1e12, 3)},
         }

@@ -36,6 +36,14 @@ CONV_CASES = [
     ("fc7x7", 37, 256, 7, 7, 1024, 7, 1, 0, True, 0, -1, 0),
     ("fc_small_m", 3, 256, 10, 10, 128, 10, 1, 0, False, 0, -1, 0),
     ("big_k", 1, 2048, 6, 10, 512, 1, 1, 0, True, 0, -1, 0),
+    # the remaining tile shapes: 32-deep 64x64 / 128x32, and the 8-wave two-k-group 64x64 shapes (64- and 128-deep steps),
+    # with ragged M, odd step counts, a residual and a split on top
+    ("t64_k32", 1, 96, 21, 27, 192, 3, 1, 1, True, 1, 4, 0),
+    ("t128x32_k32", 2, 64, 13, 19, 40, 1, 1, 0, False, 0, 5, 0),
+    ("w8_k64", 1, 160, 23, 29, 132, 3, 1, 1, True, 1, 6, 0),
+    ("w8_k128", 1, 288, 18, 22, 256, 1, 1, 0, True, 2, 7, 0),
+    ("w8_k128_3x3", 2, 64, 15, 17, 64, 3, 2, 1, False, 0, 7, 0),
+    ("w8_split", 1, 512, 9, 11, 128, 3, 1, 1, True, 1, 6, 3),
 ]
 
 

@@ -34,10 +34,10 @@ for (name, B, H, W, Cin, Cout, K, st, pad) in SHAPES:
     y = torch.empty(B, OH, OW, Cout, device=dev)
     ws = torch.empty(16 * M * Cout + 16, device=dev)
     res = []
-    for cfg in (0, 1, 3):
+    for cfg in ((0, 1, 3) if PREC else (0, 1, 2, 3, 4, 5, 6, 7)):
         if cfg == 0 and Cout < 128:
             continue
-        for sk in (1, 2, 4, 8, 16):
+        for sk in (1, 2, 3, 4, 6, 8, 16):
             d.cfg, d.splitk = cfg, sk
             steps = K * ((K * Cin + 31) // 32)
             if sk > max(1, steps // 2):
@@ -59,4 +59,4 @@ for (name, B, H, W, Cin, Cout, K, st, pad) in SHAPES:
             us = e0.elapsed_time(e1) * 1000 / n
             res.append((us, cfg, sk))
     res.sort()
-    print("%-8s M=%6d N=%5d K=%5d  best: %s" % (name, M, Cout, K * K * Cin, "  ".join("cfg%d/sk%d %.1fus %.0fTF" % (c, s, u, flops / u / 1e6) for u, c, s in res[:5])))
+    print("%-8s M=%6d N=%5d K=%5d  best: %s" % (name, M, Cout, K * K * Cin, "  ".join("cfg%d/sk%d %.1fus %.0fTF" % (c, s, u, flops / u / 1e6) for u, c, s in res[:7])))
