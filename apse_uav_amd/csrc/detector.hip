@@ -42,7 +42,9 @@ int apse_k_box_candidates(const float*, int, int, const float*, const int*, int,
 int apse_k_pack_detections(const float*, const float*, const int*, const int*, int, int, int, float*, float*, int*, int*,
                            int*, int*, int*, hipStream_t);
 int apse_k_roi_align(const FpnMaps*, const float*, const int*, const int*, const int*, int, int, int, void*, int, hipStream_t);
-int apse_k_roi_pool(const void*, int, int, int, const float*, const int*, const int*, int, int, float, float*, hipStream_t);
+int apse_k_roi_pool(const void*, int, int, int, const float*, const int*, const int*, int, int, float, float*, int, int, hipStream_t);
+int apse_k_mask_resize(const uint8_t*, int, int, int, int, int, float*, hipStream_t);
+int apse_k_roi_align_masked(const void*, int, int, int, int, const float*, const float*, int, int, int, float, float*, hipStream_t);
 int apse_k_l2_normalize(const float*, float*, int, const int*, int, hipStream_t);
 int apse_k_sqdist(const float*, const float*, int, int, int, float*, hipStream_t);
 int apse_k_mask_paste(const PasteParams*, int, int*, int*, hipStream_t);
@@ -100,6 +102,7 @@ struct apse_ctx {
     // mask tail
     uint64_t* bits = nullptr; unsigned long long* sums = nullptr; unsigned long long* cp_keys = nullptr; int wpr = 0;
     float* emb_raw = nullptr;
+    float* rf_mask = nullptr; size_t rf_mask_floats = 0;      // apse_roi_features: masks at p2 resolution (grown on demand)
     bool box_maxc_clean = false;
     int hint_total = 8;      // detections seen in the previous forward: sizes the tiles of the packed-list GEMMs
     // per-kernel profiling with HIP events on the caller's stream (bench.py roofline)
@@ -658,6 +661,7 @@ void apse_destroy(apse_ctx* c) {
     if (!c) return;
     hipSetDevice(c->cfg.device);
     for (void* p : c->allocs) hipFree(p);
+    if (c->rf_mask) hipFree(c->rf_mask);
     delete c;
 }
 
@@ -857,7 +861,7 @@ int apse_embed(apse_ctx* c, int batch, void* stream) {
     int* total = (int*)(r + c->lay.total);
     const Tens& p2 = c->t["p2"];
     int rc = apse_k_roi_pool(p2.p, p2.st, p2.H, p2.W, (float*)(r + c->lay.box), (int*)(r + c->lay.img), total, NM, g.assoc_roi,
-                             g.assoc_scale, c->t["assoc_pooled"].p, s);
+                             g.assoc_scale, (float*)c->t["assoc_pooled"].p, 0, 0, s);
     if (rc) return fail(c, rc, "roi_pool launch failed");
     rc = run_plan(c, c->embedfc, batch, s);
     if (rc) return rc;
@@ -953,6 +957,35 @@ int apse_export_feature(apse_ctx* c, const char* name, float* dst, int batch, vo
     const Tens& t = it->second;
     int rc = apse_k_nhwc_to_nchw(t.p, dst, batch, t.H * t.W, t.C, t.st, (hipStream_t)stream);
     return rc ? fail(c, rc, "export launch failed") : APSE_OK;
+}
+
+int apse_roi_features(apse_ctx* c, int image, const float* rois, const uint8_t* masks, int n, int roi_size, float* out, void* stream) {
+    if (!c || !c->finalized) return fail(c, APSE_E_STATE, "not finalized");
+    const apse_config& g = c->cfg;
+    if (image < 0 || image >= g.max_batch || n < 0 || roi_size < 1 || roi_size > 32 || (n > 0 && (!rois || !out)))
+        return fail(c, APSE_E_INVALID, "bad roi_features arguments");
+    if (n == 0) return APSE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const Tens& p2 = c->t["p2"];
+    // spatial_scale = feature width / original width (roi_features_generator.py:105; the padded width, like rcnn_tracker.py:165)
+    const float scale = (float)p2.W / (float)g.frame_w;
+    int rc;
+    if (!masks) {
+        rc = apse_k_roi_pool(p2.p, p2.st, p2.H, p2.W, rois, nullptr, nullptr, n, roi_size, scale, out, image, 1, s);
+        return rc ? fail(c, rc, "roi_pool launch failed") : APSE_OK;
+    }
+    const size_t need = (size_t)n * p2.H * p2.W;
+    if (need > c->rf_mask_floats) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (c->rf_mask) hipFree(c->rf_mask);
+        c->rf_mask = nullptr; c->rf_mask_floats = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&c->rf_mask), need * sizeof(float)) != hipSuccess) return fail(c, APSE_E_NOMEM, "roi_features scratch");
+        c->rf_mask_floats = need;
+    }
+    rc = apse_k_mask_resize(masks, n, g.frame_h, g.frame_w, p2.H, p2.W, c->rf_mask, s);
+    if (rc) return fail(c, rc, "mask resize launch failed");
+    rc = apse_k_roi_align_masked(p2.p, p2.st, p2.H, p2.W, image, rois, c->rf_mask, n, roi_size, 4, scale, out, s);
+    return rc ? fail(c, rc, "masked roi_align launch failed") : APSE_OK;
 }
 
 int apse_debug_tensor(apse_ctx* c, const char* name, void* dst, size_t max_bytes, size_t* bytes, void* stream) {
@@ -1086,7 +1119,7 @@ int apse_roi_pool(const float* feat, int H, int W, const float* rois, const int*
     if (!total_dev) hipMalloc(reinterpret_cast<void**>(&total_dev), sizeof(int));
     hipMemcpyAsync(total_dev, &n, sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream);
     hipStreamSynchronize((hipStream_t)stream);
-    return apse_k_roi_pool(feat, 0, H, W, rois, roi_img, total_dev, n, out_size, scale, out, (hipStream_t)stream);
+    return apse_k_roi_pool(feat, 0, H, W, rois, roi_img, total_dev, n, out_size, scale, out, 0, 0, (hipStream_t)stream);
 }
 
 int apse_nms_rank(const float* boxes, const float* scores, const int* valid, int n, int cat_div, int cat_mod, int ncat, float thr,

@@ -88,39 +88,129 @@ __global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const flo
 }
 
 // torchvision roi_pool forward on one NHWC map; rois in original-frame pixels, packed list.
+// One BLOCK per output bin: the four waves take the bin's rows round-robin (a bin of a frame-sized box covers hundreds
+// of cells), two cells per iteration in flight, and meet in LDS for the final max.  roi_img == nullptr: every roi
+// reads image img0; total == nullptr: all n_max rois are live; nchw: write [roi][C][R][R] (the layout
+// RoiFeaturesGenerator returns) instead of [roi][R][R][C].
 __global__ __launch_bounds__(256) void roi_pool_nhwc(const void* __restrict__ feat, int st, int H, int W,
                                                      const float* __restrict__ rois, const int* __restrict__ roi_img,
                                                      const int* __restrict__ total, int n_max, int R, float scale,
-                                                     float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
+                                                     float* __restrict__ out, int img0, int nchw) {
+    __shared__ f32x4 part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rr = R * R;
-    const int live = (*total < n_max ? *total : n_max) * rr;
-    for (int bin = blockIdx.x * 4 + (threadIdx.x >> 6); bin < live; bin += gridDim.x * 4) {
-    const int r = bin / rr;
-    const int pb = bin - r * rr;
-    const int ph = pb / R, pw = pb - ph * R;
-    const size_t f = (size_t)roi_img[r] * H * W * 256 + lane * 4;
-    const int sw = (int)roundf(rois[r * 4 + 0] * scale), sh = (int)roundf(rois[r * 4 + 1] * scale);
-    const int ew = (int)roundf(rois[r * 4 + 2] * scale), eh = (int)roundf(rois[r * 4 + 3] * scale);
-    const int rw = (ew - sw + 1) > 1 ? (ew - sw + 1) : 1;
-    const int rh = (eh - sh + 1) > 1 ? (eh - sh + 1) : 1;
-    const float bh = (float)rh / (float)R, bw = (float)rw / (float)R;
-    int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);
-    int ws = (int)floorf((float)pw * bw), we = (int)ceilf((float)(pw + 1) * bw);
-    hs = min(max(hs + sh, 0), H); he = min(max(he + sh, 0), H);
-    ws = min(max(ws + sw, 0), W); we = min(max(we + sw, 0), W);
-    const bool empty = (he <= hs) || (we <= ws);
-    const float init = empty ? 0.f : -FLT_MAX;
-    f32x4 m = {init, init, init, init};
-    for (int y = hs; y < he; ++y)
-        for (int x = ws; x < we; ++x) {
-            const f32x4 v = apse_ld4(feat, f + ((size_t)y * W + x) * 256, st);
+    const int nl = total ? (*total < n_max ? *total : n_max) : n_max;
+    const int live = nl * rr;
+    for (int bin = blockIdx.x; bin < live; bin += gridDim.x) {
+        const int r = bin / rr;
+        const int pb = bin - r * rr;
+        const int ph = pb / R, pw = pb - ph * R;
+        const size_t f = (size_t)(roi_img ? roi_img[r] : img0) * H * W * 256 + lane * 4;
+        const int sw = (int)roundf(rois[r * 4 + 0] * scale), sh = (int)roundf(rois[r * 4 + 1] * scale);
+        const int ew = (int)roundf(rois[r * 4 + 2] * scale), eh = (int)roundf(rois[r * 4 + 3] * scale);
+        const int rw = (ew - sw + 1) > 1 ? (ew - sw + 1) : 1;
+        const int rh = (eh - sh + 1) > 1 ? (eh - sh + 1) : 1;
+        const float bh = (float)rh / (float)R, bw = (float)rw / (float)R;
+        int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);
+        int ws = (int)floorf((float)pw * bw), we = (int)ceilf((float)(pw + 1) * bw);
+        hs = min(max(hs + sh, 0), H); he = min(max(he + sh, 0), H);
+        ws = min(max(ws + sw, 0), W); we = min(max(we + sw, 0), W);
+        const bool empty = (he <= hs) || (we <= ws);
+        f32x4 m = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+        auto mx = [&](const f32x4 v) {
             m[0] = v[0] > m[0] ? v[0] : m[0];
             m[1] = v[1] > m[1] ? v[1] : m[1];
             m[2] = v[2] > m[2] ? v[2] : m[2];
             m[3] = v[3] > m[3] ? v[3] : m[3];
+        };
+        for (int y = hs + wave; y < he; y += 4) {
+            int x = ws;
+            for (; x + 1 < we; x += 2) {
+                const f32x4 v0 = apse_ld4(feat, f + ((size_t)y * W + x) * 256, st);
+                const f32x4 v1 = apse_ld4(feat, f + ((size_t)y * W + x + 1) * 256, st);
+                mx(v0);
+                mx(v1);
+            }
+            if (x < we) mx(apse_ld4(feat, f + ((size_t)y * W + x) * 256, st));
         }
-    *reinterpret_cast<f32x4*>(out + ((size_t)r * rr + pb) * 256 + lane * 4) = m;
+        part[wave][lane] = m;
+        __syncthreads();
+        if (wave == 0) {
+            mx(part[1][lane]); mx(part[2][lane]); mx(part[3][lane]);
+            if (empty) m = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (nchw) {
+                for (int k = 0; k < 4; ++k) out[((size_t)r * 256 + lane * 4 + k) * rr + pb] = m[k];
+            } else {
+                *reinterpret_cast<f32x4*>(out + ((size_t)r * rr + pb) * 256 + lane * 4) = m;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// F.interpolate(mask.float(), size=(OH, OW), mode='bilinear') with align_corners=False
+// (dcnn/engines/roi_features_generator.py:99-101): src = max(0, (dst + 0.5) * in/out - 0.5), clamped neighbours.
+__global__ __launch_bounds__(256) void mask_resize_bilinear(const uint8_t* __restrict__ masks, int n, int H, int W, int OH, int OW,
+                                                            float* __restrict__ out) {
+    const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+    const size_t total = (size_t)n * OH * OW;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int ox = (int)(e % OW);
+        const int oy = (int)((e / OW) % OH);
+        const int i = (int)(e / ((size_t)OW * OH));
+        float fy = sh * ((float)oy + 0.5f) - 0.5f;
+        float fx = sw * ((float)ox + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const uint8_t* mp = masks + (size_t)i * H * W;
+        const float v00 = mp[(size_t)y0 * W + x0] ? 1.f : 0.f, v01 = mp[(size_t)y0 * W + x1] ? 1.f : 0.f;
+        const float v10 = mp[(size_t)y1 * W + x0] ? 1.f : 0.f, v11 = mp[(size_t)y1 * W + x1] ? 1.f : 0.f;
+        out[e] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    }
+}
+
+// torchvision.ops.roi_align (aligned=False, sampling_ratio = SR) over feat * mask[roi]
+// (dcnn/engines/roi_features_generator.py:102-111; the same branch is rcnn_tracker.py:166-180).  One wave per bin.
+// rois: frame pixels; mask: [n][H][W] f32 at feature resolution; out: [roi][256][R][R].
+__global__ __launch_bounds__(256) void roi_align_masked(const void* __restrict__ feat, int st, int H, int W, int img0,
+                                                        const float* __restrict__ rois, const float* __restrict__ mask,
+                                                        int n, int R, int SR, float scale, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int rr = R * R;
+    for (int bin = blockIdx.x * 4 + (threadIdx.x >> 6); bin < n * rr; bin += gridDim.x * 4) {
+        const int r = bin / rr;
+        const int pb = bin - r * rr;
+        const int ph = pb / R, pw = pb - ph * R;
+        const size_t f = (size_t)img0 * H * W * 256 + lane * 4;
+        const float* mk = mask + (size_t)r * H * W;
+        const float x1 = rois[r * 4 + 0] * scale, y1 = rois[r * 4 + 1] * scale;
+        const float x2 = rois[r * 4 + 2] * scale, y2 = rois[r * 4 + 3] * scale;
+        const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+        const float bw = rw / (float)R, bh = rh / (float)R;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int iy = 0; iy < SR; ++iy) {
+            const float yy = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)SR;
+            for (int ix = 0; ix < SR; ++ix) {
+                const float xx = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)SR;
+                if (yy < -1.f || yy > (float)H || xx < -1.f || xx > (float)W) continue;
+                float y = yy <= 0.f ? 0.f : yy, x = xx <= 0.f ? 0.f : xx;
+                int yl = (int)y, xl = (int)x, yh, xh;
+                if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+                if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                const f32x4 v1 = apse_ld4(feat, f + ((size_t)yl * W + xl) * 256, st) * mk[(size_t)yl * W + xl];
+                const f32x4 v2 = apse_ld4(feat, f + ((size_t)yl * W + xh) * 256, st) * mk[(size_t)yl * W + xh];
+                const f32x4 v3 = apse_ld4(feat, f + ((size_t)yh * W + xl) * 256, st) * mk[(size_t)yh * W + xl];
+                const f32x4 v4 = apse_ld4(feat, f + ((size_t)yh * W + xh) * 256, st) * mk[(size_t)yh * W + xh];
+                acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+            }
+        }
+        acc = acc / (float)(SR * SR);
+        for (int k = 0; k < 4; ++k) out[((size_t)r * 256 + lane * 4 + k) * rr + pb] = acc[k];
     }
 }
 
@@ -157,11 +247,27 @@ int apse_k_roi_align(const FpnMaps* F, const float* rois, const int* roi_img, co
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_roi_pool(const void* feat, int st, int H, int W, const float* rois, const int* roi_img, const int* total, int n_max,
-                    int R, float scale, float* out, hipStream_t s) {
-    int blocks = (n_max * R * R + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+                    int R, float scale, float* out, int img0, int nchw, hipStream_t s) {
+    if (n_max <= 0) return APSE_OK;
+    int blocks = n_max * R * R;
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(roi_pool_nhwc, dim3(blocks), dim3(256), 0, s, feat, st, H, W, rois, roi_img, total, n_max, R, scale,
-                       out);
+                       out, img0, nchw);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_mask_resize(const uint8_t* masks, int n, int H, int W, int OH, int OW, float* out, hipStream_t s) {
+    if (n <= 0) return APSE_OK;
+    size_t blocks = ((size_t)n * OH * OW + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mask_resize_bilinear, dim3((unsigned)blocks), dim3(256), 0, s, masks, n, H, W, OH, OW, out);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_roi_align_masked(const void* feat, int st, int H, int W, int img0, const float* rois, const float* mask, int n, int R,
+                            int SR, float scale, float* out, hipStream_t s) {
+    if (n <= 0) return APSE_OK;
+    int blocks = (n * R * R + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(roi_align_masked, dim3(blocks), dim3(256), 0, s, feat, st, H, W, img0, rois, mask, n, R, SR, scale, out);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_l2_normalize(const float* x, float* y, int D, const int* total, int n_max, hipStream_t s) {

@@ -122,6 +122,13 @@ int apse_set_detections(apse_ctx* ctx, const float* boxes_host, const int* class
 int apse_mask_tail(apse_ctx* ctx, int batch, void* stream);
 /* roi_pool(p2) + AssociationHead (rcnn_tracker.py:156-189, association_head.py:16-27). */
 int apse_embed(apse_ctx* ctx, int batch, void* stream);
+/* RoiFeaturesGenerator.get_rois_features (dcnn/engines/roi_features_generator.py:68-117), to be called after
+ * apse_backbone: RoI features of image `image` of the batch on p2 for the association-head training batches.
+ * rois_dev: [n][4] x1,y1,x2,y2 in ORIGINAL-frame pixels.  masks_dev == NULL: torchvision roi_pool (:113);
+ * else [n][frame_h][frame_w] u8 (non-zero = inside): p2 * bilinear-resized mask, then roi_align(aligned=False,
+ * sampling_ratio=4) (:95-111).  out_dev: f32 [n][256][roi_size][roi_size]. */
+int apse_roi_features(apse_ctx* ctx, int image, const float* rois_dev, const uint8_t* masks_dev, int n, int roi_size,
+                      float* out_dev, void* stream);
 /* backbone + rpn + box_head + mask_tail + embed. */
 int apse_forward(apse_ctx* ctx, int batch, void* stream);
 

@@ -309,3 +309,62 @@ def dense_mask(window, rect, img_h, img_w):
     if x1 > x0 and y1 > y0:
         m[y0:y1, x0:x1] = window
     return m
+
+
+# --------------------------------------------------------------------------- legacy roi_align
+def roi_align_legacy(feat, rois5, out_size, spatial_scale, sampling_ratio):
+    """torchvision 0.6 ops.roi_align forward (aligned=False), the call of
+    dcnn/engines/roi_features_generator.py:111 and dcnn/engines/rcnn_tracker.py:180 (sampling_ratio=4).
+
+    feat [B, C, H, W]; rois5 [n, 5] = (batch, x1, y1, x2, y2) in input pixels.  torchvision/csrc/cpu/ROIAlign_cpu.cpp:
+    no half-pixel shift, roi size clamped to >= 1, a fixed sampling_ratio x sampling_ratio grid per bin, bilinear
+    samples with the (-1, size) validity window and the low/high clamp, mean over the grid.  parity unpinned:
+    torchvision is not installed here, this restates its published algorithm."""
+    B, C, H, W = feat.shape
+    n = rois5.shape[0]
+    out = torch.zeros((n, C, out_size, out_size), dtype=torch.float32)
+    r = rois5.detach().cpu().numpy().astype(np.float32)
+    sc = np.float32(spatial_scale)
+    half = np.float32(0.5)
+    g = int(sampling_ratio)
+    for k in range(n):
+        b = int(r[k, 0])
+        sw, sh = r[k, 1] * sc, r[k, 2] * sc
+        ew, eh = r[k, 3] * sc, r[k, 4] * sc
+        rw = max(np.float32(ew - sw), np.float32(1.0))
+        rh = max(np.float32(eh - sh), np.float32(1.0))
+        bw = np.float32(rw / np.float32(out_size))
+        bh = np.float32(rh / np.float32(out_size))
+        ph = np.arange(out_size, dtype=np.float32)[:, None]
+        ii = np.arange(g, dtype=np.float32)[None, :]
+        ys = (sh + ph * bh + (ii + half) * bh / np.float32(g)).astype(np.float32).reshape(-1)
+        xs = (sw + ph * bw + (ii + half) * bw / np.float32(g)).astype(np.float32).reshape(-1)
+
+        def prep(v, size):
+            valid = ~((v < -1.0) | (v > size))
+            v = np.where(v <= 0, np.float32(0), v).astype(np.float32)
+            lo = v.astype(np.int32)
+            top = lo >= size - 1
+            hi = np.where(top, size - 1, lo + 1)
+            lo = np.where(top, size - 1, lo)
+            v = np.where(top, lo.astype(np.float32), v)
+            l = (v - lo.astype(np.float32)).astype(np.float32)
+            h = (np.float32(1) - l).astype(np.float32)
+            return valid, np.clip(lo, 0, size - 1), np.clip(hi, 0, size - 1), l, h
+
+        vy, ylo, yhi, ly, hy = prep(ys, H)
+        vx, xlo, xhi, lx, hx = prep(xs, W)
+        f = feat[b]
+        f_lo = f[:, torch.from_numpy(ylo.astype(np.int64)), :]
+        f_hi = f[:, torch.from_numpy(yhi.astype(np.int64)), :]
+        xl = torch.from_numpy(xlo.astype(np.int64))
+        xh = torch.from_numpy(xhi.astype(np.int64))
+        hy_t = torch.from_numpy(hy)[None, :, None]
+        ly_t = torch.from_numpy(ly)[None, :, None]
+        hx_t = torch.from_numpy(hx)[None, None, :]
+        lx_t = torch.from_numpy(lx)[None, None, :]
+        val = (hy_t * hx_t) * f_lo[:, :, xl] + (hy_t * lx_t) * f_lo[:, :, xh] + (ly_t * hx_t) * f_hi[:, :, xl] + (ly_t * lx_t) * f_hi[:, :, xh]
+        valid = torch.from_numpy(vy)[None, :, None] & torch.from_numpy(vx)[None, None, :]
+        val = torch.where(valid, val, torch.zeros((), dtype=torch.float32))
+        out[k] = val.view(C, out_size, g, out_size, g).sum(dim=(2, 4)) / np.float32(g * g)
+    return out
