@@ -18,6 +18,7 @@
 // the MFMAs of step s and written to LDS after the MFMAs of step s+1 (an f32 MFMA k-step is
 // 1024 cycles/wave at 64x64 and 4096 at 128x128); one barrier per k-step.
 #include "apse_common.h"
+#include <type_traits>
 
 // XT = 0: x is f32 and is read through a buffer descriptor: a tap outside the image (or a k sub-step past the end)
 // gets an offset beyond the buffer, for which the hardware range check returns zeros -> the staging code has no
@@ -37,6 +38,8 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
     constexpr int SR = 32 * WK;          // rows staged per pass
     static_assert(AP >= 1 && BP >= 1 && KS % WK == 0 && (XT == 0 || WK == 1), "unsupported shape");
     constexpr int LDC = BN + 4;
+    constexpr bool DP = (XT == 0) && (TM * TN <= 2);
+    constexpr int NSET = DP ? 2 : 1;
     constexpr int STORE_AT = 4 * KS - 2;          // chunk before which the next k-slice is written to LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);   // [2][KS][BM*32]
@@ -109,7 +112,9 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
             a_base[i] = (a_pix[i] + a_iy0[i] * p.W + a_ix0[i]) << p.cin_log2;   // element offset of tap (r = 0, q = 0); only used when valid
         }
 
-        f32x4 ra[KS][AP], rb[KS][BP];
+        // DP (small tiles): two register sets, a k-step's operands are fetched TWO steps ahead and handed to LDS one step
+        // ahead, so a fetch has 1.5 steps (>= 3000 MFMA cycles) to land instead of half a step
+        f32x4 ra[NSET][KS][AP], rb[NSET][KS][BP];
         // (filter row, 32-float step inside the row) of the next k sub-step to fetch, advanced incrementally
         int ld_r, ld_q;
         {
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
         // The k-step issues its pieces one per MFMA group, pinned there with sched_barriers, so the address
         // arithmetic and the fetches ride in the gaps of the matrix pipe instead of in front of it.
         int cur_r = 0, cur_ry = 0, cur_q = 0, cur_rowoff = 0, cur_woff = 0, cur_dpx = 0;
-        auto fetch_piece = [&](int u, int j) {
+        auto fetch_piece = [&](int set, int u, int j) {
             if (j == 0) {                      // scalars of sub-step u
                 const bool live = ld_r < p.KH;
                 cur_r = live ? ld_r : p.KH - 1;
@@ -141,30 +146,30 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
                 const int px = a_ix0[j] + cur_dpx;
                 const int okm = -(int)(((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)p.W));   // all ones when the tap is inside
                 const unsigned off = (((unsigned)(a_base[j] + cur_rowoff) << 2) & (unsigned)okm) | (0xfffffff0u & ~(unsigned)okm);
-                ra[u][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+                ra[set][u][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
             } else {
-                rb[u][j - AP] = *reinterpret_cast<const f32x4*>(wrow[j - AP] + cur_woff);
+                rb[set][u][j - AP] = *reinterpret_cast<const f32x4*>(wrow[j - AP] + cur_woff);
             }
         };
-        auto store_piece = [&](int buf, int u, int j) {
+        auto store_piece = [&](int set, int buf, int u, int j) {
             if (j < AP) {
                 const int row = srow + SR * j;
                 const int ps = slot ^ ((row >> 1) & 7);
-                *reinterpret_cast<f32x4*>(As + (buf * KS + u) * BM * 32 + row * 32 + ps * 4) = ra[u][j];
+                *reinterpret_cast<f32x4*>(As + (buf * KS + u) * BM * 32 + row * 32 + ps * 4) = ra[set][u][j];
             } else {
                 const int row = srow + SR * (j - AP);
                 const int ps = slot ^ ((row >> 1) & 7);
-                *reinterpret_cast<f32x4*>(Bs + (buf * KS + u) * BN * 32 + row * 32 + ps * 4) = rb[u][j - AP];
+                *reinterpret_cast<f32x4*>(Bs + (buf * KS + u) * BN * 32 + row * 32 + ps * 4) = rb[set][u][j - AP];
             }
         };
-        auto load_step_bl = [&]() {
+        auto load_step_bl = [&](int set) {
 #pragma unroll
             for (int u = 0; u < KS; ++u)
 #pragma unroll
-                for (int j = 0; j < AP + BP; ++j) fetch_piece(u, j);
+                for (int j = 0; j < AP + BP; ++j) fetch_piece(set, u, j);
         };
         auto load_step = [&](int sb) {
-            if constexpr (XT == 0) { load_step_bl(); return; }
+            if constexpr (XT == 0) { load_step_bl(0); return; }
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
                 int ss = sb * KS + u;
@@ -182,12 +187,12 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
                         const int off = ((a_pix[i] + iy * p.W + a_ix0[i]) << p.cin_log2) + q;
                         v = apse_ld4(p.x, (size_t)off, p.x_st);      // 16-bit activations widen exactly to f32
                     }
-                    ra[u][i] = v;
+                    ra[0][u][i] = v;
                 }
 #pragma unroll
                 for (int i = 0; i < BP; ++i) {
                     const int n = n0 + srow + 32 * i;
-                    rb[u][i] = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * w_row + (size_t)r * p.KWCp + q);
+                    rb[0][u][i] = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * w_row + (size_t)r * p.KWCp + q);
                 }
             }
         };
@@ -198,13 +203,13 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
                 for (int i = 0; i < AP; ++i) {
                     const int row = srow + 32 * i;
                     const int ps = slot ^ ((row >> 1) & 7);
-                    *reinterpret_cast<f32x4*>(As + (buf * KS + u) * BM * 32 + row * 32 + ps * 4) = ra[u][i];
+                    *reinterpret_cast<f32x4*>(As + (buf * KS + u) * BM * 32 + row * 32 + ps * 4) = ra[0][u][i];
                 }
 #pragma unroll
                 for (int i = 0; i < BP; ++i) {
                     const int row = srow + 32 * i;
                     const int ps = slot ^ ((row >> 1) & 7);
-                    *reinterpret_cast<f32x4*>(Bs + (buf * KS + u) * BN * 32 + row * 32 + ps * 4) = rb[u][i];
+                    *reinterpret_cast<f32x4*>(Bs + (buf * KS + u) * BN * 32 + row * 32 + ps * 4) = rb[0][u][i];
                 }
             }
         };
@@ -231,8 +236,12 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
                 constexpr int G = 16 * KS / WK;             // MFMA groups per k-step and wave (TM*TN MFMAs each)
                 constexpr int SP = (G / 2) / NP > 0 ? (G / 2) / NP : 1;
                 static_assert(NP * SP <= G / 2 + SP - 1 && G / 2 + (NP - 1) * SP < G, "piece schedule does not fit the k-step");
-                for (int sb = s_begin; sb < s_end; ++sb) {
-                    const int buf = (sb - s_begin) & 1;
+                if constexpr (DP) load_step_bl(1);          // operands of the second step, in flight across the first
+                // one k-step; PAR = parity of the step inside this K slice = LDS buffer it reads
+                auto kstep = [&](auto PAR) {
+                    constexpr int buf = decltype(PAR)::value;
+                    constexpr int FS = DP ? buf : 0;          // register set the fetches of this step fill
+                    constexpr int SS = DP ? (buf ^ 1) : 0;    // register set handed to LDS buffer buf^1 in this step
                     f32x4 af[2][TM], bf[2][TN];
                     auto load_frags = [&](int cc, int fb) {
                         const int u = (cc >> 2) * WK + kg, c = cc & 3;      // this wave group's sub-steps only
@@ -257,16 +266,17 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int g = cc * 4 + k;
-                            // first half of the step: fetch piece g/SP of step sb+1 (unconditional: a dead step past the end
-                            // reads zeros / the next K slice and is never consumed); second half: hand it to LDS buf^1
+                            // first half of the step: fetch piece g/SP of the step after next (DP) / the next step
+                            // (unconditional: a dead step past the end reads zeros / the next K slice and is never
+                            // consumed); second half: hand the NEXT step's operands to LDS buffer buf^1
                             if (g % SP == 0 && g / SP < NP) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                fetch_piece((g / SP) / (AP + BP), (g / SP) % (AP + BP));
+                                fetch_piece(FS, (g / SP) / (AP + BP), (g / SP) % (AP + BP));
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                             if (g >= G / 2 && (g - G / 2) % SP == 0 && (g - G / 2) / SP < NP) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                store_piece(buf ^ 1, ((g - G / 2) / SP) / (AP + BP), ((g - G / 2) / SP) % (AP + BP));
+                                store_piece(SS, buf ^ 1, ((g - G / 2) / SP) / (AP + BP), ((g - G / 2) / SP) % (AP + BP));
                                 __builtin_amdgcn_sched_barrier(0);
                             }
 #pragma unroll
@@ -277,6 +287,10 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
                         }
                     }
                     __syncthreads();
+                };
+                for (int sb = s_begin; sb < s_end; sb += 2) {
+                    kstep(std::integral_constant<int, 0>{});
+                    if (sb + 1 < s_end) kstep(std::integral_constant<int, 1>{});
                 }
             } else
             for (int sb = s_begin; sb < s_end; ++sb) {
@@ -608,9 +622,9 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0
 
 // Tile/split heuristic (tools/conv_sweep.py on MI355X): fill >= ~2 resident blocks per CU; prefer the
 // largest tile that does; for small-M layers trade tile size against split-K:
-//   very large K -> 128x128 tiles with the K range split across blocks (fc1, res5 3x3),
+//   very large K -> 128x128 tiles with the K range split across blocks (fc1),
 //   medium K  -> 64x64 tiles (unsplit once there are >= 192 of them: res4 3x3 / 1x1); with about one tile per CU
-//                the 8-wave two-k-group shape (cfg 7), which puts two waves on each SIMD,
+//                the 8-wave two-k-group shape (cfg 6), which puts two waves on each SIMD,
 //   tiny K, wide N (res4 conv3) -> 128x64 tiles.
 int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk) {
     *splitk = 1;
@@ -625,23 +639,23 @@ int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk) {
     if (Cout <= 64) return tiles(128, 64) >= 192 ? 3 : 1;
     const int t128 = tiles(128, 128);
     if (t128 >= 224) {
-        if (t128 < 384 && steps <= 16 && tiles(128, 64) >= 384) return 3;
+        if (t128 < 384 && tiles(128, 64) >= 384) return 3;      // ~one 128x128 tile per CU: 128x64 gives every CU two blocks
         return 0;
     }
-    if (t128 >= 32 && steps >= 128) {
+    if (t128 >= 32 && steps >= 256) {                            // fc1: K = 12544
         *splitk = split_for(t128, 8);
         return 0;
     }
     const int t64 = tiles(64, 64);
-    if (t64 >= 192) return t64 <= 320 ? 7 : 1;     // about one 64x64 tile per CU: the 8-wave shape keeps two waves on every SIMD
+    if (t64 >= 192) return t64 <= 320 ? 6 : 1;     // about one 64x64 tile per CU: the 8-wave shape keeps two waves on every SIMD
     if (steps >= 16) {
-        // 8-wave blocks, K split so that there is about one block per CU (each split keeps >= 8 steps)
+        // 8-wave blocks, K split so that there is about one block per CU (each slice keeps >= 8 steps)
         int sk = (256 + t64 / 2) / t64;
-        if (t64 > 64 && sk > 2) sk = 2;            // 65..191 tiles: two slices measured best (mask head, res5 1x1)
+        if (t64 > 64 && sk > 2) sk = 2;            // 65..191 tiles: two slices measured best (mask head, res5)
         if (sk > steps / 8) sk = steps / 8;
         if (sk > 64) sk = 64;
         *splitk = sk < 1 ? 1 : sk;
-        return 7;
+        return 6;
     }
     return 1;
 }

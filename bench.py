@@ -27,6 +27,11 @@ sys.path.insert(0, ROOT)
 
 CFG_NAMES = ["conv_igemm<128x128>", "conv_igemm<64x64>", "conv_igemm<128x32>", "conv_igemm<128x64>",
              "conv_igemm<64x64,k32>", "conv_igemm<128x32,k32>", "conv_igemm<64x64,8 waves,k64>", "conv_igemm<64x64,8 waves,k128>"]
+# template arguments <WM, WN, TM, TN, KS, XT, WK> of conv_igemm_f32 behind each tile shape (f32 path, f32 activations):
+# the kernel names rocprofv3 reports, used to look the dominant kernel up in the committed PMC summary
+CFG_TEMPLATE = ["<2, 2, 2, 2, 1, 0, 1>", "<2, 2, 1, 1, 2, 0, 1>", "<4, 1, 1, 1, 2, 0, 1>", "<4, 1, 1, 2, 1, 0, 1>",
+                "<2, 2, 1, 1, 1, 0, 1>", "<4, 1, 1, 1, 1, 0, 1>", "<2, 2, 1, 1, 2, 0, 2>", "<2, 2, 1, 1, 4, 0, 2>"]
+PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_latest.json")
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 dense
 
@@ -233,6 +238,19 @@ def main():
         achieved = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         total_conv_ms = float(prof[:, 0].sum())
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so this is
+        # the committed summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same workload
+        # (tools/gpu_profile_round.sh; read side doubled per the gfx950 note of MI355X_MICROARCH.md)
+        traffic, traffic_src = None, None
+        if args.dtype == "f32" and B == 1 and os.path.exists(PMC_TRAFFIC_FILE):
+            try:
+                with open(PMC_TRAFFIC_FILE) as fh:
+                    pm = json.load(fh).get("conv_igemm_f32" + CFG_TEMPLATE[dom])
+                if pm:
+                    traffic = int(pm["fetch_bytes"] + pm["write_bytes"])
+                    traffic_src = "profiles/pmc_traffic_latest.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, bytes per launch"
+            except (OSError, ValueError, KeyError):
+                pass
         flops_frame = model.flops(1, P_sum / max(args.steps * B, 1), N_sum / max(args.steps * B, 1))
         out = {
             "metric": "4K UAV frames/sec (whole node)", "value": round(fps, 3), "unit": "frames/s", "n_gpus": world,
@@ -246,7 +264,7 @@ def main():
                        "gflop_per_frame_algorithmic": round(flops_frame / 1e9, 2)},
             "roofline": {"bound": "mfma", "kernel": CFG_NAMES[dom], "achieved": round(achieved, 3),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": None, "avg_launch_ms": round(ms / max(nl, 1), 5), "launches": int(nl),
+                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(ms / max(nl, 1), 5), "launches": int(nl),
                          "all_kernels": {CFG_NAMES[k]: {"ms": round(float(prof[k, 0]), 3),
                                                         "tflops": round(float(prof[k, 1] / max(prof[k, 0], 1e-9) / 1e9), 3),
                                                         "launches": int(prof[k, 2])} for k in range(8) if prof[k, 2] > 0},

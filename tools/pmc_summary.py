@@ -24,3 +24,10 @@ for k in sorted(af, key=lambda k: -af[k][0]):
     n = af[k][1]
     print('%-46s %8d %16.2f %16.2f %14.2f' % (k[:46], n, af[k][0] / n / 1024, 2 * af[k][0] / n / 1024,
                                                 aw[k][0] / max(aw[k][1], 1) / 1024))
+
+# machine-readable copy for bench.py's roofline.traffic (bytes per launch, read side already doubled)
+if len(sys.argv) > 3:
+    import json
+    json.dump({k.replace('void ', ''): {"launches": af[k][1], "fetch_bytes": 2 * af[k][0] / af[k][1] * 1024,
+                                        "write_bytes": aw[k][0] / max(aw[k][1], 1) * 1024} for k in af},
+              open(sys.argv[3], 'w'), indent=1)
