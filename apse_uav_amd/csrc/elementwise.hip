@@ -27,9 +27,15 @@ __global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ 
     const uint8_t* srow = src + (size_t)b * src_img_stride + (size_t)y * W * 3;
     const int nbytes = W * 3;
     // W*3 is a multiple of 4 for every supported width (W % 4 == 0); rows start 4-byte aligned.
-    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(srow);
-    uint32_t* r4 = reinterpret_cast<uint32_t*>(row);
-    for (int i = threadIdx.x; i < (nbytes >> 2); i += blockDim.x) r4[i] = s4[i];
+    if ((nbytes & 15) == 0) {              // 16-byte rows (W % 16 == 0, e.g. 3840): three 16-byte loads per thread, all in flight
+        const uint4* s16 = reinterpret_cast<const uint4*>(srow);
+        uint4* r16 = reinterpret_cast<uint4*>(row);
+        for (int i = threadIdx.x; i < (nbytes >> 4); i += blockDim.x) r16[i] = s16[i];
+    } else {
+        const uint32_t* s4 = reinterpret_cast<const uint32_t*>(srow);
+        uint32_t* r4 = reinterpret_cast<uint32_t*>(row);
+        for (int i = threadIdx.x; i < (nbytes >> 2); i += blockDim.x) r4[i] = s4[i];
+    }
     __syncthreads();
     uint8_t* orow = tmp + (size_t)b * tmp_img_stride + (size_t)y * OW * 3;
     for (int o = threadIdx.x; o < OW * 3; o += blockDim.x) {

@@ -305,11 +305,14 @@ __global__ __launch_bounds__(1024) void nms_scan(NmsScratch S, int* __restrict__
             const uint64_t diag = row < n ? mask[(size_t)row * 16 + ch] : 0ull;
             uint64_t rem = removed[ch];
             uint64_t keepbits = 0;
-            for (int r = 0; r < rows_here; ++r) {
-                if (!((rem >> r) & 1ull)) {
-                    keepbits |= (1ull << r);
-                    rem |= readlane64(diag, r);
-                }
+            // visit only rows that are still alive: the next kept row is the lowest clear bit of `rem` above the
+            // last one (a removed row never suppresses anything), so the loop runs once per KEPT row, not per row
+            uint64_t alive = ~rem & (rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull));
+            while (alive) {
+                const int r = __builtin_ctzll(alive);
+                keepbits |= (1ull << r);
+                rem |= readlane64(diag, r) | (1ull << r);
+                alive &= ~rem;
             }
             if ((keepbits >> lane) & 1ull) out[kept + __popcll(keepbits & ((1ull << lane) - 1ull))] = entry[row];
             kept += __popcll(keepbits);
