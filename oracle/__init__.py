@@ -22,5 +22,9 @@ Pinning status (see DESIGN.md "Oracle"):
 * everything whose arithmetic lives in detectron2 0.1.2 / torchvision 0.6 /
   OpenCV 4.2 (not installed, source not under /root/reference) is restated from
   the published algorithms: **parity unpinned** for those rows (backbone, FPN,
-  RPN, ROI heads, paste, roi_pool, undistort/Lab-gamma).
+  RPN, ROI heads, paste, roi_pool, undistort/Lab-gamma), and likewise for the
+  SURVEY 8(f) rank-4 additions: ``roi_features.py`` / ``ops.roi_align_legacy``
+  (torchvision roi_align aligned=False, F.interpolate) and ``mots.py`` (the MOTS
+  writers; pycocotools' RLE format is pinned by the example line the reference
+  quotes at dcnn/utils/mots_evaluation.py:13).
 """
