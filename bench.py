@@ -281,57 +281,44 @@ def main():
 
 
 def throughput_mode(cfg, sd, tracker, model, frames, nres, B, depth, replay, steps=24, warmup=4):
-    """Same frames, same per-frame results, `depth` frames in flight on separate streams / contexts: the
-    small-grid layers of one frame (res4/res5 at batch 1 fill ~1 block per CU) overlap with other frames'.
-    Informational: the headline value is the single-stream run above."""
-    from apse_uav_amd.networks.track_rcnn import TrackRCNN
-    models = [model]
-    for _ in range(depth - 1):
-        m2 = TrackRCNN(cfg)
-        m2.load_state_dict(sd)
-        m2.attach_association_head(tracker.association_head)
-        models.append(m2)
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(depth - 1)]
-
-    def submit(i):
-        k = i % depth
-        idx = [(i * B + j) % nres for j in range(B)]
-        batch = frames[idx] if B > 1 else frames[idx[0]:idx[0] + 1]
-        with torch.cuda.stream(streams[k]):
-            models[k].preprocess_frames(batch)
-            models[k].run(B)
-
-    def collect(i):
-        k = i % depth
-        with torch.cuda.stream(streams[k]):
-            res = models[k].read(B)
-        for b in range(B):
-            replay.step(res.record(b), i * B + b)
-
+    """Same frames, same per-frame results, `depth` frames in flight on separate streams / contexts
+    (apse_uav_amd.engines.pipelined_tracker.PipelinedRcnnTracker: detector per frame on its own stream, association
+    on the host in frame order): the small-grid layers of one frame (res4/res5 at batch 1 fill ~1 block per CU)
+    overlap with other frames'.  Informational: the headline value is the single-stream run above."""
+    from apse_uav_amd.engines.pipelined_tracker import PipelinedRcnnTracker
+    if B != 1:
+        return None
+    H, W = frames.shape[1:3]
+    drv = PipelinedRcnnTracker(cfg, (H, W), tracker.association_head.state_dict(), depth=depth, detector_state=sd)
     lat = []
     t0 = None
-    inflight = []
+    stamps = {}
+    done = 0
     for i in range(warmup + steps):
         if i == warmup:
-            while inflight:
-                collect(inflight.pop(0)[0])
+            while drv._inflight:
+                drv.collect()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        inflight.append((i, time.perf_counter()))
-        submit(i)
-        if len(inflight) == depth:
-            j, ts = inflight.pop(0)
-            collect(j)
-            if i >= warmup:
-                lat.append(time.perf_counter() - ts)
-    while inflight:
-        j, ts = inflight.pop(0)
-        collect(j)
-        lat.append(time.perf_counter() - ts)
+        if len(drv._inflight) == depth:
+            j, _ = drv.collect()
+            if j in stamps:
+                lat.append(time.perf_counter() - stamps.pop(j))
+                done += 1
+        stamps[drv._submitted] = time.perf_counter() if i >= warmup else None
+        if stamps[drv._submitted] is None:
+            stamps.pop(drv._submitted)
+        drv.submit(frames[i % nres])
+    while drv._inflight:
+        j, _ = drv.collect()
+        if j in stamps:
+            lat.append(time.perf_counter() - stamps.pop(j))
+            done += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"frames_in_flight": depth, "value": round(steps * B / dt, 3), "unit": "frames/s",
-            "p50_ms_per_frame": round(1000.0 * float(np.median(lat)) / B, 3), "steps": steps}
+    return {"frames_in_flight": depth, "value": round(done / dt, 3), "unit": "frames/s",
+            "p50_ms_per_frame": round(1000.0 * float(np.median(lat)), 3), "steps": done,
+            "engine": "PipelinedRcnnTracker"}
 
 
 def cpu_baseline(sd, asd, host_frames, blocks, H, W, nframes, max_threads):

@@ -142,6 +142,41 @@ def test_sequence_ids_and_csv(setup, logdir, tmp_path):
     assert same >= len(lines) - 1              # integer cells; a threshold-edge pixel may move one centroid by 1
 
 
+@pytest.mark.parametrize("depth,want_masks", [(3, False), (2, True)])
+def test_pipelined_tracker_equals_sequential(setup, logdir, depth, want_masks):
+    """PipelinedRcnnTracker (several frames in flight on separate streams / contexts, association on the host in
+    frame order) must give the ids, boxes, centroids and CSV lines of RcnnTracker.next_frame, frame by frame."""
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from apse_uav_amd.engines.pipelined_tracker import PipelinedRcnnTracker
+    frames = [setup["seq"].frame(t) for t in range(7)]
+    seq = RcnnTracker(setup["cfg"], FRAME, setup["asd"], detector_state=setup["sd"])
+
+    def boxes_np(rec):
+        if not len(rec):
+            return None
+        return np.stack([np.asarray((b.tensor if hasattr(b, "tensor") else torch.as_tensor(b)).cpu(), np.float32).reshape(-1)
+                         for b in rec.pred_boxes])
+    ref = []
+    for t, fr in enumerate(frames):
+        rec = seq.next_frame(fr)
+        ref.append((list(rec.ids) if len(rec) else [], boxes_np(rec),
+                    seq.log_line(rec, 1, t)[0], [m.dense().cpu().numpy() for m in rec.pred_masks] if len(rec) else []))
+    drv = PipelinedRcnnTracker(setup["cfg"], FRAME, setup["asd"], depth=depth, want_masks=want_masks, detector_state=setup["sd"])
+    n = 0
+    for (t, rec), (ids, boxes, line, masks) in zip(drv.run(frames), ref):     # log_line belongs to the frame just returned
+        assert t == n
+        n += 1
+        assert (list(rec.ids) if len(rec) else []) == ids
+        if boxes is not None:
+            assert np.array_equal(boxes_np(rec), boxes)
+        assert drv.tracker.log_line(rec, 1, t)[0] == line
+        if want_masks:
+            for a, b in zip(rec.pred_masks, masks):
+                assert np.array_equal(a.dense().cpu().numpy(), b)
+    assert n == len(frames)
+    _log(logdir, "pipelined/depth%d" % depth, dict(frames=len(frames), ids_last=ref[-1][0]))
+
+
 @pytest.mark.parametrize("storage", [True, False], ids=["store16", "store32"])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_bf16_mode_vs_bf16_oracle(setup, logdir, dtype, storage):
