@@ -8,15 +8,17 @@
 //   m = (b, oy, ox) output pixel, n = output channel, k = (r, q) with q running over the
 //   contiguous NHWC run of KW pixels x Cin channels of filter row r (so one k-step of 32 floats
 //   is one 128-byte contiguous read per output pixel; out-of-image pixels are zero-filled).
-// Block = 256 threads = 4 waves (one per SIMD); wave tile = TM x TN MFMA tiles of 32x32.
+// Block = 256 threads = 4 waves (one per SIMD), or 512 threads = two k groups of 4 waves (WK = 2); wave tile =
+// TM x TN MFMA tiles of 32x32.
 // LDS: A and B k-slices [rows][32 f32] double-buffered, 16-byte slots XOR-swizzled with
 // (row>>1)&7 so both the ds_write_b128 staging and the ds_read_b128 fragment reads are
 // bank-conflict-free (MI355X_MICROARCH.md, LDS table: b128 reads are served per 16-lane group
 // over 64 banks).  One ds_read_b128 feeds FOUR MFMA k-steps: lane half h takes k = 8c+4h+j for
 // step j (the k order inside a chunk is a free choice as long as A and B agree).
-// Global->LDS staging goes through two register sets: the loads of k-step s+2 are issued before
-// the MFMAs of step s and written to LDS after the MFMAs of step s+1 (an f32 MFMA k-step is
-// 1024 cycles/wave at 64x64 and 4096 at 128x128); one barrier per k-step.
+// Global->LDS staging goes through registers, one 16-byte "piece" per MFMA gap: the pieces of k-step s+1
+// (s+2 for the small tiles, which keep two register sets) are fetched during the first half of step s and
+// handed to LDS during its second half (an f32 MFMA k-step is 1024 cycles/wave at 64x64 and 4096 at
+// 128x128); one barrier per k-step.  See DESIGN.md section 3 for the measured effect of each choice.
 #include "apse_common.h"
 #include <type_traits>
 
