@@ -30,8 +30,21 @@
 // WK = 2: the block has 8 waves; wave group kg = wave / 4 owns the k sub-steps u with u % WK == kg of every step and
 // the groups' partial tiles are added (fixed order) in the epilogue.  For layers with about one tile per CU
 // (res4 at batch 1) this puts two waves on every SIMD without a second pass over a split-K workspace.
-template <int WM, int WN, int TM, int TN, int KS, int XT, int WK>
+// PR = 0: f32 operands (v_mfma_f32_32x32x2_f32).  PR = 1 / 2: bf16 / f16 operands already STORED in that type
+// (activations x_st == PR, filters pre-rounded in w16; v_mfma_f32_32x32x16_*): an LDS row is then 64 elements = the same
+// 128 bytes, a staged piece the same 16 bytes, so the staging, swizzle and epilogue are shared; only the element
+// count per k sub-step (64 instead of 32) and the MFMA issue differ.  (16-bit operands that must be converted from f32
+// at staging -- the stem -- and filter rows that are not a multiple of 64 elements stay on conv_igemm_bf16.hip.)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 apse_mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 apse_mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+template <int WM, int WN, int TM, int TN, int KS, int XT, int WK, int PR = 0>
 __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
+    static_assert(PR == 0 || XT == 0, "16-bit operands use the descriptor path only");
+    constexpr int EPS = PR ? 64 : 32;              // elements per k sub-step (one 128-byte LDS row)
+    constexpr int ESH = PR ? 1 : 2;                // log2(bytes per element)
+    constexpr int EPSLOT = 16 >> ESH;              // elements per 16-byte slot
     constexpr int NT = 256 * WK;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -67,17 +80,18 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
     const int z = blockIdx.y;
     // a "step" is KS sub-steps of 32 k each between two barriers (KS = 2 for the small tiles, whose
     // 1024-cycle MFMA sub-step is too short to cover an L2/HBM round trip)
-    const int steps_big = (p.steps_total + KS - 1) / KS;
+    const int steps_per_row = p.KWCp / EPS;
+    const int steps_total = PR ? p.KH * steps_per_row : p.steps_total;
+    const int steps_big = (steps_total + KS - 1) / KS;
     const int per = (steps_big + p.splitk - 1) / p.splitk;
     const int s_begin = z * per;
     const int s_end = (s_begin + per < steps_big) ? s_begin + per : steps_big;
-    const int steps_per_row = p.KWCp >> 5;
     const int ohw = p.OH * p.OW;
     const size_t w_row = (size_t)p.KH * p.KWCp;
     const bool direct = (p.splitk == 1);
     __amdgpu_buffer_rsrc_t xrsrc;
     if constexpr (XT == 0)
-        xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)(((unsigned)(p.B * p.H * p.W) << p.cin_log2) * 4u), 0x00020000);
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((((unsigned)(p.B * p.H * p.W) << p.cin_log2)) << ESH), 0x00020000);
 
     bool warm_pending = p.next_w && z == 0;     // the block's first tile also warms a slice of the next layer's filters
     // Persistent over tiles: the grid is min(tiles, cap); count-limited launches (packed detection
@@ -124,9 +138,11 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
             ld_r = ss0 / steps_per_row;
             ld_q = ss0 - ld_r * steps_per_row;
         }
-        const float* wrow[BP];
+        const char* wrow[BP];                       // byte pointers: f32 filters or the pre-rounded 16-bit copy
 #pragma unroll
-        for (int i = 0; i < BP; ++i) wrow[i] = p.w + (size_t)(n0 + srow + SR * i) * w_row + (slot << 2);
+        for (int i = 0; i < BP; ++i)
+            wrow[i] = (PR ? reinterpret_cast<const char*>(p.w16) : reinterpret_cast<const char*>(p.w)) +
+                      ((((size_t)(n0 + srow + SR * i) * w_row) + (size_t)(slot * EPSLOT)) << ESH);
         // One "piece" = one 16-byte fetch of this thread (pieces 0..AP-1: A rows, AP..AP+BP-1: B rows of sub-step u).
         // The k-step issues its pieces one per MFMA group, pinned there with sched_barriers, so the address
         // arithmetic and the fetches ride in the gaps of the matrix pipe instead of in front of it.
@@ -136,10 +152,10 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
                 const bool live = ld_r < p.KH;
                 cur_r = live ? ld_r : p.KH - 1;
                 cur_ry = live ? ld_r : (1 << 28);
-                cur_q = (ld_q << 5) + (slot << 2);
+                cur_q = ld_q * EPS + slot * EPSLOT;
                 cur_dpx = cur_q >> p.cin_log2;
                 cur_rowoff = ((cur_r * p.W) << p.cin_log2) + cur_q;
-                cur_woff = cur_r * p.KWCp + (ld_q << 5);
+                cur_woff = (cur_r * p.KWCp + ld_q * EPS) << ESH;      // bytes
                 ++ld_q;
                 if (ld_q == steps_per_row) { ld_q = 0; ++ld_r; }
             }
@@ -147,10 +163,10 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
                 const int iy = a_iy0[j] + cur_ry;            // cur_ry is far out of range on a dead sub-step
                 const int px = a_ix0[j] + cur_dpx;
                 const int okm = -(int)(((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)p.W));   // all ones when the tap is inside
-                const unsigned off = (((unsigned)(a_base[j] + cur_rowoff) << 2) & (unsigned)okm) | (0xfffffff0u & ~(unsigned)okm);
+                const unsigned off = (((unsigned)(a_base[j] + cur_rowoff) << ESH) & (unsigned)okm) | (0xfffffff0u & ~(unsigned)okm);
                 ra[set][u][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
             } else {
-                rb[set][u][j - AP] = *reinterpret_cast<const f32x4*>(wrow[j - AP] + cur_woff);
+                rb[set][u][j - AP] = *reinterpret_cast<const f32x4*>(wrow[j - AP] + cur_woff);      // 16 bytes of filter row
             }
         };
         auto store_piece = [&](int set, int buf, int u, int j) {
@@ -237,7 +253,7 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
                 constexpr int NP = KS * (AP + BP);          // fetch pieces per k-step
                 constexpr int G = 16 * KS / WK;             // MFMA groups per k-step and wave (TM*TN MFMAs each)
                 constexpr int SP = (G / 2) / NP > 0 ? (G / 2) / NP : 1;
-                static_assert(NP * SP <= G / 2 + SP - 1 && G / 2 + (NP - 1) * SP < G, "piece schedule does not fit the k-step");
+                static_assert(PR != 0 || (NP * SP <= G / 2 + SP - 1 && G / 2 + (NP - 1) * SP < G), "piece schedule does not fit the k-step");
                 if constexpr (DP) load_step_bl(1);          // operands of the second step, in flight across the first
                 // one k-step; PAR = parity of the step inside this K slice = LDS buffer it reads
                 auto kstep = [&](auto PAR) {
@@ -262,6 +278,37 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
                         }
                     };
                     load_frags(0, 0);
+                    if constexpr (PR != 0) {
+                        // 16-bit operands: one MFMA per (chunk, tile) -- the gaps are counted per MFMA and may carry
+                        // more than one piece (a 64-deep sub-step is a quarter of the f32 step's matrix time)
+                        typedef typename std::conditional<PR == 1, bf16x8, f16x8>::type op8;
+                        constexpr int MPC = TM * TN;
+                        constexpr int NG = (4 * KS / WK) * MPC;
+                        constexpr int PPG = (NP + NG / 2 - 1) / (NG / 2);
+#pragma unroll
+                        for (int cc = 0; cc < 4 * KS / WK; ++cc) {
+                            if (cc + 1 < 4 * KS / WK) load_frags(cc + 1, (cc + 1) & 1);
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) {
+                                    const int g = cc * MPC + i * TN + j;
+                                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                    for (int q = 0; q < PPG; ++q) {
+                                        const int pc = (g < NG / 2 ? g : g - NG / 2) * PPG + q;
+                                        if (pc < NP) {
+                                            if (g < NG / 2) fetch_piece(FS, pc / (AP + BP), pc % (AP + BP));
+                                            else store_piece(SS, buf ^ 1, pc / (AP + BP), pc % (AP + BP));
+                                        }
+                                    }
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    acc[i][j] = apse_mfma16(__builtin_bit_cast(op8, af[cc & 1][i]), __builtin_bit_cast(op8, bf[cc & 1][j]), acc[i][j]);
+                                }
+                        }
+                        __syncthreads();
+                        return;
+                    }
 #pragma unroll
                     for (int cc = 0; cc < 4 * KS / WK; ++cc) {
                         if (cc + 1 < 4 * KS / WK) load_frags(cc + 1, (cc + 1) & 1);
@@ -545,7 +592,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvParams p) {
     }
 }
 
-template <int WM, int WN, int TM, int TN, int KS, int XT, int WK = 1>
+template <int WM, int WN, int TM, int TN, int KS, int XT, int WK = 1, int PR = 0>
 static int launch_cfg_x(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
@@ -553,7 +600,7 @@ static int launch_cfg_x(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipE
     const size_t lds = lds_stage > lds_c ? lds_stage : lds_c;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, KS, XT, WK>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, KS, XT, WK, PR>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
@@ -570,7 +617,7 @@ static int launch_cfg_x(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipE
         if (grid_x > want) grid_x = want;
     }
     if (ev0) hipEventRecord(ev0, s);
-    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, KS, XT, WK>), dim3(grid_x, p.splitk), dim3(256 * WK), lds, s, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, KS, XT, WK, PR>), dim3(grid_x, p.splitk), dim3(256 * WK), lds, s, p);
     if (ev1) hipEventRecord(ev1, s);
     if (p.splitk > 1 && !p.tile_cnt) {
         const size_t total = (size_t)p.M * p.Cout;
@@ -598,6 +645,25 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0
     if (p.M <= 0 || p.Cout <= 0 || p.steps_total <= 0) return APSE_E_INVALID;
     if (p.res_mode != 0 && (p.Cout & 3) != 0) return APSE_E_INVALID;      // residual rows are read as float4
     if (p.prec == 1 || p.prec == 2) {
+        // operands already stored 16-bit, filter rows a whole number of 64-element steps: the scheduled kernel
+        const bool fast16 = p.w16 && p.x_st == p.prec && (p.KWCp & 63) == 0 && p.cin_log2 >= 3 &&
+                            ((((size_t)p.B * p.H * p.W) << p.cin_log2) * 2 < 0xfffffff0ull) && !p.tile_cnt;
+        if (fast16) {
+            int rc = APSE_E_INVALID;
+            const int c16 = (cfg == 4 || cfg == 5 || cfg == 2) ? 1 : (cfg == 7 ? 6 : cfg);
+            if (p.prec == 1) {
+                if (c16 == 0) rc = launch_cfg_x<2, 2, 2, 2, 1, 0, 1, 1>(p, s, ev0, ev1);
+                else if (c16 == 1) rc = launch_cfg_x<2, 2, 1, 1, 2, 0, 1, 1>(p, s, ev0, ev1);
+                else if (c16 == 3) rc = launch_cfg_x<4, 1, 1, 2, 1, 0, 1, 1>(p, s, ev0, ev1);
+                else if (c16 == 6) rc = launch_cfg_x<2, 2, 1, 1, 2, 0, 2, 1>(p, s, ev0, ev1);
+            } else {
+                if (c16 == 0) rc = launch_cfg_x<2, 2, 2, 2, 1, 0, 1, 2>(p, s, ev0, ev1);
+                else if (c16 == 1) rc = launch_cfg_x<2, 2, 1, 1, 2, 0, 1, 2>(p, s, ev0, ev1);
+                else if (c16 == 3) rc = launch_cfg_x<4, 1, 1, 2, 1, 0, 1, 2>(p, s, ev0, ev1);
+                else if (c16 == 6) rc = launch_cfg_x<2, 2, 1, 1, 2, 0, 2, 2>(p, s, ev0, ev1);
+            }
+            return rc;              // launch_cfg_x adds the split-K reduce pass itself
+        }
         if (ev0) hipEventRecord(ev0, s);
         int rc = apse_launch_conv_bf16(p, cfg, s);
         if (ev1) hipEventRecord(ev1, s);

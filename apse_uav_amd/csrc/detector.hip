@@ -44,6 +44,7 @@ int apse_k_pack_detections(const float*, const float*, const int*, const int*, i
 int apse_k_roi_align(const FpnMaps*, const float*, const int*, const int*, const int*, int, int, int, void*, int, hipStream_t);
 int apse_k_roi_pool(const void*, int, int, int, const float*, const int*, const int*, int, int, float, float*, int, int, hipStream_t);
 int apse_k_mask_resize(const uint8_t*, int, int, int, int, int, float*, hipStream_t);
+int apse_k_round16(const float*, uint16_t*, size_t, int, hipStream_t);
 int apse_k_roi_align_masked(const void*, int, int, int, int, const float*, const float*, int, int, int, float, float*, hipStream_t);
 int apse_k_l2_normalize(const float*, float*, int, const int*, int, hipStream_t);
 int apse_k_sqdist(const float*, const float*, int, int, int, float*, hipStream_t);
@@ -177,6 +178,19 @@ struct ConvSpec {
 
 // 16-bit storage mode: every activation the bulk GEMMs produce lives in HBM in the operand type; the narrow
 // decision heads (Cout <= 32) and the association FC keep f32 outputs.
+// f32 -> bf16 (dtype 1) / f16 (dtype 2) bits, round-to-nearest-even like the in-kernel converts; a NaN stays a NaN
+static uint16_t round16(float v, int dtype) {
+    if (dtype == 2) {
+        const _Float16 hval = (_Float16)v;
+        uint16_t r;
+        memcpy(&r, &hval, 2);
+        return r;
+    }
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    if ((b & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((b >> 16) | 0x40);
+    return (uint16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+}
 static int storage_type(const apse_ctx* c) { return (c->cfg.compute_dtype >= 1 && c->cfg.storage16) ? c->cfg.compute_dtype : 0; }
 
 static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, const Tens& in, int in_items_mult, Tens* out,
@@ -256,17 +270,7 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     if (use_bf16) {
         // filters pre-rounded to the 16-bit operand type (round-to-nearest-even, as the in-kernel converts do)
         std::vector<uint16_t> p16(packed.size());
-        for (size_t i = 0; i < packed.size(); ++i) {
-            if (c->cfg.compute_dtype == 2) {
-                const _Float16 hval = (_Float16)packed[i];
-                memcpy(&p16[i], &hval, 2);
-                continue;
-            }
-            uint32_t b;
-            memcpy(&b, &packed[i], 4);
-            if ((b & 0x7fffffffu) > 0x7f800000u) p16[i] = (uint16_t)((b >> 16) | 0x40);       // NaN stays NaN
-            else p16[i] = (uint16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
-        }
+        for (size_t i = 0; i < packed.size(); ++i) p16[i] = round16(packed[i], c->cfg.compute_dtype);
         wd16 = dupload(c, p16);
     } else {
         wd = dupload(c, packed);
@@ -1083,6 +1087,22 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
         if (!cnt) { if (hipMalloc(reinterpret_cast<void**>(&cnt), 65536 * sizeof(int)) != hipSuccess) return APSE_E_NOMEM; hipMemset(cnt, 0, 65536 * sizeof(int)); }
         p.tile_cnt = cnt;
     }
+    if (!p.prec) return apse_launch_conv(p, cfg, (hipStream_t)stream);
+    // 16-bit operands: round the filters like a context does at load (this stateless entry is a test / tool helper: the
+    // rounded copy is rebuilt by a small kernel on the caller's stream in front of every call, in a buffer that only grows)
+    const size_t ne = (size_t)apse_roundup(p.Cout, 128) * p.KH * p.KWCp;
+    static uint16_t* d16 = nullptr;
+    static size_t d16_cap = 0;
+    if (ne > d16_cap) {
+        hipDeviceSynchronize();
+        if (d16) hipFree(d16);
+        d16 = nullptr; d16_cap = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&d16), ne * 2) != hipSuccess) return APSE_E_NOMEM;
+        d16_cap = ne;
+    }
+    int rc = apse_k_round16(w, d16, ne, p.prec, (hipStream_t)stream);
+    if (rc) return rc;
+    p.w16 = d16;
     return apse_launch_conv(p, cfg, (hipStream_t)stream);
 }
 

@@ -153,7 +153,19 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw(const void* __restrict__ x, 
     }
 }
 
+// f32 -> bf16 (dtype 1) / f16 (dtype 2), round-to-nearest-even (v_cvt_pk_bf16_f32 / v_cvt_f16_f32), NaN stays NaN
+__global__ __launch_bounds__(256) void round16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, size_t n, int dtype) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) apse_st1(y, i, x[i], dtype);
+}
+
 extern "C" {
+int apse_k_round16(const float* x, uint16_t* y, size_t n, int dtype, hipStream_t s) {
+    if (n == 0) return APSE_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(round16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, n, dtype);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
 int apse_k_pil_resize(const uint8_t* src, uint8_t* tmp, float* out, uint8_t* resized_u8, const int* hb, const int* hc,
                       int hk, const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,
                       const float* mean, hipStream_t s) {
