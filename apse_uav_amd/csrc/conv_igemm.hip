@@ -40,17 +40,17 @@ __device__ __forceinline__ f32x16 apse_mfma16(bf16x8 a, bf16x8 b, f32x16 c) { re
 __device__ __forceinline__ f32x16 apse_mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 template <int WM, int WN, int TM, int TN, int KS, int XT, int WK, int PR = 0>
-__global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvParams p) {
     static_assert(PR == 0 || XT == 0, "16-bit operands use the descriptor path only");
     constexpr int EPS = PR ? 64 : 32;              // elements per k sub-step (one 128-byte LDS row)
     constexpr int ESH = PR ? 1 : 2;                // log2(bytes per element)
     constexpr int EPSLOT = 16 >> ESH;              // elements per 16-byte slot
-    constexpr int NT = 256 * WK;
+    constexpr int NT = 64 * WM * WN * WK;          // WM x WN waves per k group (4, or 8 for the 256x128 tile)
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int AP = BM / (32 * WK);   // staging passes (32*WK rows x 8 slots of 16 B per pass)
-    constexpr int BP = BN / (32 * WK);
-    constexpr int SR = 32 * WK;          // rows staged per pass
+    constexpr int SR = NT / 8;           // rows staged per pass (8 slots of 16 B per row)
+    constexpr int AP = BM / SR;          // staging passes
+    constexpr int BP = BN / SR;
     static_assert(AP >= 1 && BP >= 1 && KS % WK == 0 && (XT == 0 || WK == 1), "unsupported shape");
     constexpr int LDC = BN + 4;
     constexpr bool DP = (XT == 0) && (TM * TN <= 2);
@@ -215,6 +215,13 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32(const ConvParams p) {
             }
         };
         auto store_step = [&](int buf) {
+            if constexpr (XT == 0) {               // the piece form knows the block's row stride (SR)
+#pragma unroll
+                for (int u = 0; u < KS; ++u)
+#pragma unroll
+                    for (int j = 0; j < AP + BP; ++j) store_piece(0, buf, u, j);
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
 #pragma unroll
@@ -617,7 +624,7 @@ static int launch_cfg_x(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipE
         if (grid_x > want) grid_x = want;
     }
     if (ev0) hipEventRecord(ev0, s);
-    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, KS, XT, WK, PR>), dim3(grid_x, p.splitk), dim3(256 * WK), lds, s, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, KS, XT, WK, PR>), dim3(grid_x, p.splitk), dim3(64 * WM * WN * WK), lds, s, p);
     if (ev1) hipEventRecord(ev1, s);
     if (p.splitk > 1 && !p.tile_cnt) {
         const size_t total = (size_t)p.M * p.Cout;
@@ -650,17 +657,22 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0
                             ((((size_t)p.B * p.H * p.W) << p.cin_log2) * 2 < 0xfffffff0ull) && !p.tile_cnt;
         if (fast16) {
             int rc = APSE_E_INVALID;
-            const int c16 = (cfg == 4 || cfg == 5 || cfg == 2) ? 1 : (cfg == 7 ? 6 : cfg);
+            int c16 = (cfg == 4 || cfg == 5 || cfg == 2) ? 1 : (cfg == 7 ? 6 : cfg);
+            // deep-K layers with at least one 256x128 tile per CU: the wider tile halves the filter traffic per FLOP
+            // (out2 / rpn_t2 / res4 3x3 at batch 8: +5..7 %)
+            if (c16 == 0 && p.steps_total >= 32 && ((p.M + 255) / 256) * ((p.Cout + 127) / 128) >= 250) c16 = 8;
             if (p.prec == 1) {
                 if (c16 == 0) rc = launch_cfg_x<2, 2, 2, 2, 1, 0, 1, 1>(p, s, ev0, ev1);
                 else if (c16 == 1) rc = launch_cfg_x<2, 2, 1, 1, 2, 0, 1, 1>(p, s, ev0, ev1);
                 else if (c16 == 3) rc = launch_cfg_x<4, 1, 1, 2, 1, 0, 1, 1>(p, s, ev0, ev1);
                 else if (c16 == 6) rc = launch_cfg_x<2, 2, 1, 1, 2, 0, 2, 1>(p, s, ev0, ev1);
+                else if (c16 == 8) rc = launch_cfg_x<4, 2, 2, 2, 1, 0, 1, 1>(p, s, ev0, ev1);      // 256x128, 8 waves
             } else {
                 if (c16 == 0) rc = launch_cfg_x<2, 2, 2, 2, 1, 0, 1, 2>(p, s, ev0, ev1);
                 else if (c16 == 1) rc = launch_cfg_x<2, 2, 1, 1, 2, 0, 1, 2>(p, s, ev0, ev1);
                 else if (c16 == 3) rc = launch_cfg_x<4, 1, 1, 2, 1, 0, 1, 2>(p, s, ev0, ev1);
                 else if (c16 == 6) rc = launch_cfg_x<2, 2, 1, 1, 2, 0, 2, 2>(p, s, ev0, ev1);
+                else if (c16 == 8) rc = launch_cfg_x<4, 2, 2, 2, 1, 0, 1, 2>(p, s, ev0, ev1);
             }
             return rc;              // launch_cfg_x adds the split-K reduce pass itself
         }
@@ -684,6 +696,7 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0
         case 5: return launch_cfg<4, 1, 1, 1, 1>(p, s, ev0, ev1);     // 128x32, 32-deep steps
         case 6: return launch_cfg_k2<2, 2, 1, 1, 2, 2>(p, s, ev0, ev1);  // 64x64, 8 waves: two k groups, 64-deep steps
         case 7: return launch_cfg_k2<2, 2, 1, 1, 4, 2>(p, s, ev0, ev1);  // 64x64, 8 waves, 128-deep steps
+        case 8: return launch_cfg<2, 2, 2, 2, 1>(p, s, ev0, ev1);        // (256x128 exists for 16-bit operands only)
         default: return APSE_E_INVALID;
     }
 }

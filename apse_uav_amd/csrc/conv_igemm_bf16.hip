@@ -380,6 +380,7 @@ static int launch_et(const ConvParams& p, int cfg, hipStream_t s) {
         case 4: return launch_bf16<ET, 2, 2, 1, 1, 2>(p, s);      // the f32 kernel's extra shapes map to their nearest 16-bit one
         case 5: return launch_bf16<ET, 4, 1, 1, 1, 2>(p, s);
         case 6: case 7: return launch_bf16<ET, 2, 2, 1, 1, 2>(p, s);
+        case 8: return launch_bf16<ET, 2, 2, 2, 2, 1>(p, s);
         default: return APSE_E_INVALID;
     }
 }

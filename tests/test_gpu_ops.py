@@ -44,6 +44,9 @@ CONV_CASES = [
     ("w8_k128", 1, 288, 18, 22, 256, 1, 1, 0, True, 2, 7, 0),
     ("w8_k128_3x3", 2, 64, 15, 17, 64, 3, 2, 1, False, 0, 7, 0),
     ("w8_split", 1, 512, 9, 11, 128, 3, 1, 1, True, 1, 6, 3),
+    # 256x128 tile (8 waves as 4x2; 16-bit operands only -- the f32 path maps it to 128x128): ragged M, two n tiles, residual
+    ("t256x128", 1, 128, 40, 52, 256, 3, 1, 1, True, 1, 8, 0),
+    ("t256x128_1x1", 2, 256, 33, 31, 384, 1, 1, 0, False, 0, 8, 0),
 ]
 
 

@@ -46,8 +46,8 @@ for (name, B, H, W, Cin, Cout, K, st, pad) in SHAPES:
     rsd = torch.randn(B, OH, OW, Cout, device=dev).to(tdt) if RES else None
     ws = torch.empty(16 * M * Cout + 16, device=dev)
     res = []
-    for cfg in ((0, 1, 3, 6) if PREC else (0, 1, 2, 3, 4, 5, 6, 7)):
-        if cfg == 0 and Cout < 128:
+    for cfg in ((0, 1, 3, 6, 8) if (PREC and ST16) else (0, 1, 3, 6) if PREC else (0, 1, 2, 3, 4, 5, 6, 7)):
+        if cfg in (0, 8) and Cout < 128:
             continue
         for sk in (1, 2, 3, 4, 6, 8, 16):
             d.cfg, d.splitk = cfg, sk
