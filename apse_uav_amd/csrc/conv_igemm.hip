@@ -42,6 +42,9 @@ __device__ __forceinline__ f32x16 apse_mfma16(f16x8 a, f16x8 b, f32x16 c) { retu
 template <int WM, int WN, int TM, int TN, int KS, int XT, int WK, int PR = 0>
 __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvParams p) {
     static_assert(PR == 0 || XT == 0, "16-bit operands use the descriptor path only");
+    // XT = 2 / 3: descriptor path with bf16 / f16 activations WIDENED to f32 operands (the exact-f32 decision heads of the
+    // 16-bit modes: RPN logits / deltas, box predictor, mask logits): 8-byte fetches of 4 elements, widened on the way to LDS
+    constexpr bool DESC = XT != 1;
     constexpr int EPS = PR ? 64 : 32;              // elements per k sub-step (one 128-byte LDS row)
     constexpr int ESH = PR ? 1 : 2;                // log2(bytes per element)
     constexpr int EPSLOT = 16 >> ESH;              // elements per 16-byte slot
@@ -51,9 +54,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvPa
     constexpr int SR = NT / 8;           // rows staged per pass (8 slots of 16 B per row)
     constexpr int AP = BM / SR;          // staging passes
     constexpr int BP = BN / SR;
-    static_assert(AP >= 1 && BP >= 1 && KS % WK == 0 && (XT == 0 || WK == 1), "unsupported shape");
+    static_assert(AP >= 1 && BP >= 1 && KS % WK == 0 && (DESC || WK == 1), "unsupported shape");
     constexpr int LDC = BN + 4;
-    constexpr bool DP = (XT == 0) && (TM * TN <= 2);
+    constexpr bool DP = DESC && (TM * TN <= 2);
     constexpr int NSET = DP ? 2 : 1;
     constexpr int STORE_AT = 4 * KS - 2;          // chunk before which the next k-slice is written to LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,8 +93,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvPa
     const size_t w_row = (size_t)p.KH * p.KWCp;
     const bool direct = (p.splitk == 1);
     __amdgpu_buffer_rsrc_t xrsrc;
-    if constexpr (XT == 0)
-        xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((((unsigned)(p.B * p.H * p.W) << p.cin_log2)) << ESH), 0x00020000);
+    if constexpr (DESC)
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((((unsigned)(p.B * p.H * p.W) << p.cin_log2)) << (XT >= 2 ? 1 : ESH)), 0x00020000);
 
     bool warm_pending = p.next_w && z == 0;     // the block's first tile also warms a slice of the next layer's filters
     // Persistent over tiles: the grid is min(tiles, cap); count-limited launches (packed detection
@@ -163,8 +166,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvPa
                 const int iy = a_iy0[j] + cur_ry;            // cur_ry is far out of range on a dead sub-step
                 const int px = a_ix0[j] + cur_dpx;
                 const int okm = -(int)(((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)p.W));   // all ones when the tap is inside
-                const unsigned off = (((unsigned)(a_base[j] + cur_rowoff) << ESH) & (unsigned)okm) | (0xfffffff0u & ~(unsigned)okm);
-                ra[set][u][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+                if constexpr (XT >= 2) {             // 4 elements of 2 bytes; widened in store_piece, once the data has landed
+                    const unsigned off = (((unsigned)(a_base[j] + cur_rowoff) << 1) & (unsigned)okm) | (0xfffffff0u & ~(unsigned)okm);
+                    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)off, 0, 0);
+                    ra[set][u][j] = f32x4{__uint_as_float(raw[0]), __uint_as_float(raw[1]), 0.f, 0.f};
+                } else {
+                    const unsigned off = (((unsigned)(a_base[j] + cur_rowoff) << ESH) & (unsigned)okm) | (0xfffffff0u & ~(unsigned)okm);
+                    ra[set][u][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+                }
             } else {
                 rb[set][u][j - AP] = *reinterpret_cast<const f32x4*>(wrow[j - AP] + cur_woff);      // 16 bytes of filter row
             }
@@ -173,7 +182,16 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvPa
             if (j < AP) {
                 const int row = srow + SR * j;
                 const int ps = slot ^ ((row >> 1) & 7);
-                *reinterpret_cast<f32x4*>(As + (buf * KS + u) * BM * 32 + row * 32 + ps * 4) = ra[set][u][j];
+                f32x4 v = ra[set][u][j];
+                if constexpr (XT == 2) {             // bf16 pairs -> f32
+                    const unsigned lo = __float_as_uint(v[0]), hi = __float_as_uint(v[1]);
+                    v = f32x4{__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+                } else if constexpr (XT == 3) {      // f16 pairs -> f32
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const h2 a = __builtin_bit_cast(h2, __float_as_uint(v[0])), b = __builtin_bit_cast(h2, __float_as_uint(v[1]));
+                    v = f32x4{(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+                }
+                *reinterpret_cast<f32x4*>(As + (buf * KS + u) * BM * 32 + row * 32 + ps * 4) = v;
             } else {
                 const int row = srow + SR * (j - AP);
                 const int ps = slot ^ ((row >> 1) & 7);
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvPa
                 for (int j = 0; j < AP + BP; ++j) fetch_piece(set, u, j);
         };
         auto load_step = [&](int sb) {
-            if constexpr (XT == 0) { load_step_bl(0); return; }
+            if constexpr (DESC) { load_step_bl(0); return; }
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
                 int ss = sb * KS + u;
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvPa
             }
         };
         auto store_step = [&](int buf) {
-            if constexpr (XT == 0) {               // the piece form knows the block's row stride (SR)
+            if constexpr (DESC) {                  // the piece form knows the block's row stride (SR)
 #pragma unroll
                 for (int u = 0; u < KS; ++u)
 #pragma unroll
@@ -256,7 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvPa
             store_step(0);
             if (warm_now) apse_warm_retire(warm);
             __syncthreads();
-            if constexpr (XT == 0) {
+            if constexpr (DESC) {
                 constexpr int NP = KS * (AP + BP);          // fetch pieces per k-step
                 constexpr int G = 16 * KS / WK;             // MFMA groups per k-step and wave (TM*TN MFMAs each)
                 constexpr int SP = (G / 2) / NP > 0 ? (G / 2) / NP : 1;
@@ -690,7 +708,12 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0
     switch (cfg) {
         case 0: return launch_cfg<2, 2, 2, 2, 1>(p, s, ev0, ev1);
         case 1: return launch_cfg<2, 2, 1, 1, 2>(p, s, ev0, ev1);
-        case 2: return launch_cfg<4, 1, 1, 1, 2>(p, s, ev0, ev1);
+        case 2: {                                                        // the Cout <= 32 heads: also fed by 16-bit activations
+            const bool small = (((size_t)p.B * p.H * p.W) << p.cin_log2) * 4 < 0xfffffff0ull;
+            if (small && p.x_st == 1 && p.cin_log2 >= 2) return launch_cfg_x<4, 1, 1, 1, 2, 2>(p, s, ev0, ev1);
+            if (small && p.x_st == 2 && p.cin_log2 >= 2) return launch_cfg_x<4, 1, 1, 1, 2, 3>(p, s, ev0, ev1);
+            return launch_cfg<4, 1, 1, 1, 2>(p, s, ev0, ev1);
+        }
         case 3: return launch_cfg<4, 1, 1, 2, 1>(p, s, ev0, ev1);
         case 4: return launch_cfg<2, 2, 1, 1, 1>(p, s, ev0, ev1);     // 64x64, 32-deep steps: 32 KB of LDS, up to 4-5 blocks per CU
         case 5: return launch_cfg<4, 1, 1, 1, 1>(p, s, ev0, ev1);     // 128x32, 32-deep steps
