@@ -80,6 +80,8 @@ def main(argv=None):
     ap.add_argument("--vehicle-ids", default="2,3,4")
     ap.add_argument("--out", default="seq_dcnn_data.csv")
     ap.add_argument("--raw-out", default="")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="single process: frames in flight on separate streams (engines/pipelined_tracker.py); 1 = plain loop")
     args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,8 +106,26 @@ def main(argv=None):
     cfg = setup_cfg(device="cuda:%d" % local)
     cfg.APSE.MAX_BATCH = args.batch
     cfg.APSE.DTYPE = args.dtype
-    tracker = RcnnTracker(cfg, (H, W), asd, detector_state=sd)
     n, get_frame = frame_source(args, H, W)
+    if world == 1 and args.in_flight > 1:
+        import time
+        from apse_uav_amd.engines.pipelined_tracker import PipelinedRcnnTracker
+        assert args.batch == 1, "--in-flight drives batch-1 frames"
+        drv = PipelinedRcnnTracker(cfg, (H, W), asd, depth=args.in_flight, detector_state=sd)
+        lines, max_id = [], 0
+        t0 = time.perf_counter()
+        for t, objs in drv.run(get_frame(k) for k in range(n)):
+            line, hi_id = drv.tracker.log_line(objs, args.host_id, t)
+            lines.append(line)
+            max_id = max(max_id, hi_id)
+        dt = time.perf_counter() - t0
+        csv_log.write_consumer_csv(args.out, lines, args.host_id, [int(v) for v in args.vehicle_ids.split(",")])
+        if args.raw_out:
+            csv_log.write_raw_csv(args.raw_out, lines, args.host_id, max_id)
+        print("wrote %s: %d frames, %d track ids, %d frames in flight, %.1f frames/s incl. frame generation and upload"
+              % (args.out, len(lines), max_id, args.in_flight, n / dt))
+        return
+    tracker = RcnnTracker(cfg, (H, W), asd, detector_state=sd)
     lo, hi = shard_frames(n, rank, world)
     recs = detect_range(tracker, get_frame, lo, hi, args.batch)
     if world > 1:
