@@ -642,7 +642,7 @@ static int build_plan(apse_ctx* c) {
 // ================================================================================================ C ABI
 extern "C" {
 
-const char* apse_version(void) { return "apse_hip 0.2 (gfx950, f32 / bf16 MFMA)"; }
+const char* apse_version(void) { return "apse_hip 0.3 (gfx950, f32 / bf16 / f16 MFMA)"; }
 
 int apse_create(const apse_config* cfg, apse_ctx** out) {
     if (!cfg || !out) return fail(nullptr, APSE_E_INVALID, "null argument");

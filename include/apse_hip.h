@@ -159,8 +159,9 @@ typedef struct apse_conv_desc {
     int Cout, KH, KW, stride, pad;
     int relu;
     int res_mode;           /* 0 none, 1 same-shape residual, 2 nearest-2x upsampled residual */
-    int cfg;                /* -1 auto, else tile shape 0..7: 128x128, 64x64, 128x32, 128x64 (64-deep steps for the small
-                               ones), 4/5 = 64x64 / 128x32 with 32-deep steps, 6/7 = 64x64 with 8 waves in two k groups */
+    int cfg;                /* -1 auto, else tile shape 0..8: 128x128, 64x64, 128x32, 128x64 (64-deep steps for the small
+                               ones), 4/5 = 64x64 / 128x32 with 32-deep steps, 6/7 = 64x64 with 8 waves in two k groups, 8 = 256x128
+                               (16-bit operands stored 16-bit only; otherwise 128x128) */
     int splitk;             /* 0 auto */
     int prec;               /* 0 f32 MFMA; 1 bf16 / 2 f16 MFMA (operands rounded at LDS staging, f32 accumulate) */
     int fuse_reduce;        /* split-K: 1 = last-arriving block reduces in the launch, 0 = separate reduce kernel */
