@@ -7,7 +7,9 @@ each on its own HIP stream and detector context (weights replicated, ~250 MB eac
 the host strictly in frame order from each frame's results block -- the same split a frame-sharded multi-GPU run
 uses, inside one GPU.  Small-grid layers of one frame (res4 / res5 at batch 1 have one tile per CU)
 then overlap with other frames' work: ~175 vs ~155 frames/s at 3840x2160 on one MI355X, at ``depth`` x the
-per-frame latency.  Results are identical to ``RcnnTracker.next_frame`` frame by frame (tests/test_gpu_detector.py).
+per-frame latency (measured: depth 2 / 3 / 4 = 176 / 180 / 183 frames/s; depth 6 collapses to 45 -- more streams than
+the device serves concurrently only add queue switching, so keep depth <= 4).  Results are identical to
+``RcnnTracker.next_frame`` frame by frame (tests/test_gpu_detector.py; a 48-frame 4K sequence gives the same CSV).
 
     drv = PipelinedRcnnTracker(config, image_size, weights, depth=3, detector_state=sd)
     for frame_idx, objects in drv.run(frames):              # frames: iterable of HxWx3 uint8 BGR arrays
@@ -24,7 +26,7 @@ from .rcnn_tracker import RcnnTracker, instances_from_record
 
 class PipelinedRcnnTracker:
     def __init__(self, config, image_size, weights, depth=3, want_masks=False, detector_state=None, **tracker_kwargs):
-        assert depth >= 1
+        assert 1 <= depth <= 4, "depth 2..4 (more frames in flight than the device runs concurrently is slower, see the module text)"
         self.tracker = RcnnTracker(config, image_size, weights, detector_state=detector_state, **tracker_kwargs)
         self.depth = depth
         self.want_masks = want_masks
