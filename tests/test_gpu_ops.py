@@ -407,3 +407,40 @@ def test_undistort_gamma(golden_dir, logdir):
     # gamma LUT and the inverse transform: rare pixels differ by a few levels
     assert diff.max() <= 6 and (diff > 0).mean() < 1e-3
     assert (full.astype(np.int32).mean() < frame.astype(np.int32).mean())                  # gamma 2 darkens
+
+
+def test_c_abi_rejects_bad_arguments():
+    """Every export returns a negative APSE_E_* code on bad input (no exception crosses the ABI, nothing is launched)."""
+    import ctypes as C
+    from apse_uav_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad = 1, 8, 8, 24, 16, 1, 1, 1, 0      # Cin not a power of two
+    d.cfg, d.splitk = -1, 0
+    x = torch.zeros(1, 8, 8, 32, device="cuda")
+    w = torch.zeros(128 * 32, device="cuda")
+    y = torch.zeros(1, 8, 8, 16, device="cuda")
+    s = _lib.stream_ptr()
+    assert lib.apse_conv2d(C.byref(d), _lib.ptr(x), _lib.ptr(w), None, None, _lib.ptr(y), None, 0, s) < 0
+    d.Cin = 32
+    d.cfg = 11                                                                                   # no such tile shape
+    assert lib.apse_conv2d(C.byref(d), _lib.ptr(x), _lib.ptr(w), None, None, _lib.ptr(y), None, 0, s) < 0
+    d.cfg, d.splitk, d.Cin = 1, 4, 256                                                           # split-K without a workspace
+    x2 = torch.zeros(1, 8, 8, 256, device="cuda")
+    w2 = torch.zeros(128 * 256, device="cuda")
+    assert lib.apse_conv2d(C.byref(d), _lib.ptr(x2), _lib.ptr(w2), None, None, _lib.ptr(y), None, 0, s) < 0
+    d.Cin = 32
+    d.cfg, d.splitk, d.res_mode, d.Cout = -1, 0, 1, 18                                           # residual rows need Cout % 4 == 0
+    assert lib.apse_conv2d(C.byref(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(y), _lib.ptr(y), None, 0, s) < 0
+    d.res_mode, d.Cout, d.prec, d.x_st = 0, 16, 1, 2                                             # f16 storage with bf16 operands
+    assert lib.apse_conv2d(C.byref(d), _lib.ptr(x), _lib.ptr(w), None, None, _lib.ptr(y), None, 0, s) < 0
+    assert lib.apse_conv2d(None, _lib.ptr(x), _lib.ptr(w), None, None, _lib.ptr(y), None, 0, s) < 0
+    # context-level calls on a null / unfinished context
+    assert lib.apse_backbone(None, 1, s) < 0
+    assert lib.apse_roi_features(None, 0, None, None, 1, 8, None, s) < 0
+    cfg = _lib.Config()
+    cfg.struct_size = 4                                                                          # wrong struct size
+    ctx = C.c_void_p()
+    assert lib.apse_create(C.byref(cfg), C.byref(ctx)) < 0 and not ctx.value
+    assert b"size" in lib.apse_last_error(None)
+    torch.cuda.synchronize()
