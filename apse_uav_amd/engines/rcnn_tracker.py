@@ -28,7 +28,7 @@ from ..utils import csv_log
 from ..weights import load_association_file
 from .track_predictor import TrackPredictor
 
-## TODO - put them in config   (kept from the reference, rcnn_tracker.py:32-34)
+# module-level constants, as in the reference (rcnn_tracker.py:32-34 keeps them outside the config too)
 ASSOCIATION_ROI_SIZE = 10
 
 
