@@ -49,54 +49,63 @@ class ObjectInstances(Instances):
             ret.set(k, v)
         return ret
 
+    # ---- table-driven field handling: which per-object lists exist, and where each value comes from
+    #  * bookkeeping fields get a fixed value whenever an object is (re)detected,
+    #  * detection fields are copied from the detection that was associated,
+    #  * ``scores`` is copied only when the object is created (frozen afterwards, reference :146-152),
+    #  * ``embeddings`` exist only when the tracker supplies them.
+    _ON_DETECTION = (("detected_this_frame", True), ("frames_since_detected", 0))
+    _COPIED_ALWAYS = ("pred_boxes", "pred_classes", "pred_masks")
+    _COPIED_AT_BIRTH = ("scores",)
+
+    def _ensure_lists(self, with_embeddings):
+        if len(self) != 0:
+            return
+        for name in _FIELDS:
+            if name == "embeddings" and not with_embeddings:
+                continue
+            self._fields[name] = MaskList() if name == "pred_masks" else []
+
+    @staticmethod
+    def _detection_value(name, det_fields, detection_id, fresh_box):
+        v = det_fields[name][detection_id]
+        if name == "pred_boxes" and fresh_box:
+            v = SetBoxes(v.tensor)            # an object owns its box (a detection's Boxes row is a view)
+        return v
+
     def add_new_object(self, detection_id, detections, detection_embeddings=None, verbose=True):
-        d = detections.get_fields()
-        o = self._fields
+        det_fields = detections.get_fields()
         new_id = self.get_new_id()
         if verbose and "new_objects" in self._display_info:
             print("adding detection_id: {} as new object with id: {}".format(detection_id, new_id))
-        if len(self) == 0:
-            o["detected_this_frame"] = []
-            o["ids"] = []
-            o["frames_since_detected"] = []
-            o["pred_boxes"] = []
-            o["scores"] = []
-            o["pred_classes"] = []
-            o["pred_masks"] = MaskList()
-            if detection_embeddings is not None:
-                o["embeddings"] = []
-        o["detected_this_frame"].append(True)
-        o["ids"].append(new_id)
-        o["frames_since_detected"].append(0)
-        o["pred_boxes"].append(SetBoxes(d["pred_boxes"][detection_id].tensor))
-        o["scores"].append(d["scores"][detection_id])
-        o["pred_classes"].append(d["pred_classes"][detection_id])
-        o["pred_masks"].append(d["pred_masks"][detection_id])
-        if detection_embeddings is not None and "embeddings" in o:
-            o["embeddings"].append(detection_embeddings[detection_id])
+        self._ensure_lists(detection_embeddings is not None)
+        store = self._fields
+        for name, value in self._ON_DETECTION:
+            store[name].append(value)
+        store["ids"].append(new_id)
+        for name in self._COPIED_ALWAYS + self._COPIED_AT_BIRTH:
+            store[name].append(self._detection_value(name, det_fields, detection_id, fresh_box=True))
+        if detection_embeddings is not None and "embeddings" in store:
+            store["embeddings"].append(detection_embeddings[detection_id])
         self._assigned_ids.append(new_id)
 
     def delete_undetected_objects(self, frames_threshold):
-        if len(self) == 0:
-            return
-        drop = [k for k in range(len(self)) if self.frames_since_detected[k] > frames_threshold]
-        for k in sorted(drop, reverse=True):
-            for name in _FIELDS:
-                if name in self._fields:
-                    del self._fields[name][k]
+        stale = [k for k in range(len(self)) if self.frames_since_detected[k] > frames_threshold]
+        for k in reversed(stale):
+            for column in self._fields.values():
+                del column[k]
 
     def associate_detection(self, detection_id, object_index, detections, detections_embeddings=None):
         if "associations" in self._display_info:
             print("associating detection {} to object id: {}".format(detection_id, self.ids[object_index]))
-        d = detections.get_fields()
-        o = self._fields
-        o["detected_this_frame"][object_index] = True
-        o["frames_since_detected"][object_index] = 0
-        o["pred_boxes"][object_index] = d["pred_boxes"][detection_id]
-        o["pred_classes"][object_index] = d["pred_classes"][detection_id]
-        o["pred_masks"][object_index] = d["pred_masks"][detection_id]
-        if "embeddings" in o and detections_embeddings is not None:
-            o["embeddings"][object_index] = detections_embeddings[detection_id]
+        det_fields = detections.get_fields()
+        store = self._fields
+        for name, value in self._ON_DETECTION:
+            store[name][object_index] = value
+        for name in self._COPIED_ALWAYS:
+            store[name][object_index] = self._detection_value(name, det_fields, detection_id, fresh_box=False)
+        if "embeddings" in store and detections_embeddings is not None:
+            store["embeddings"][object_index] = detections_embeddings[detection_id]
 
     def finish_association(self):
         if len(self) == 0:
