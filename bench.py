@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP-event timing (no roofline block)")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=8,
                     help="HIP-event pairs around every convolution launch on every n-th timed step (each pair costs "
                          "~5 us of stream time, ~1.5 ms per fully instrumented frame)")
     ap.add_argument("--cpu-threads", type=int, default=32)
