@@ -9,7 +9,7 @@ points, roi_pool + association embedding, D2H of the results block, host associa
 CSV line.  N > 1: one process per GPU, frames sharded by rank (weak scaling), a single gather of the
 per-frame records to rank 0 after the last step, which then runs the sequential id assignment.
 
-Prints ONE JSON line (see the contract in the task description), plus
+Prints ONE JSON line (metric, value, unit, n_gpus, steps, warmup, ms_per_step, scaling, dtype, data, config, ...), plus
   roofline     : the dominant kernel's algorithmic FLOP/s measured with HIP events inside the timed region
   cpu_baseline : the CPU oracle (oracle/, PyTorch CPU f32) timed on this host, rank 0, N = 1 only.
 """
