@@ -67,6 +67,7 @@ struct Tens { float* p = nullptr; int H = 0, W = 0, C = 0; int st = 0; };   // p
 struct ConvStep {
     ConvParams p;          // B/M filled at launch
     int b_mult = 1;        // items per image (1, post_topk, dets_per_image)
+    int fixed_items = 0;   // > 0: the launch always covers this many items (a tensor laid out for max_batch: merged RPN head)
     int cfg = 0;
     double flops_per_item = 0;   // algorithmic 2*MACs per item (one image / one roi / one detection)
     int count_kind = 0;    // 0 none, 1 prop_cnt[0] (batch 1 only), 2 packed total
@@ -195,7 +196,7 @@ static int storage_type(const apse_ctx* c) { return (c->cfg.compute_dtype >= 1 &
 
 static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, const Tens& in, int in_items_mult, Tens* out,
                     const std::string& out_name, const Tens* res, int res_mode, int y_ld_override, int count_kind,
-                    float* out_ptr_override = nullptr) {
+                    float* out_ptr_override = nullptr, const Tens* out_view = nullptr) {
     // gather rows
     std::vector<float> rows;    // OIHW concatenated
     std::vector<float> bias;
@@ -301,10 +302,11 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     p.cdec = sp.deconv ? Cout / 4 : 0;
     const int out_c = sp.deconv ? Cout / 4 : (y_ld_override > 0 ? y_ld_override : Cout);
     const int oh = sp.deconv ? 2 * p.OH : p.OH, ow = sp.deconv ? 2 * p.OW : p.OW;
-    const int out_st = (use_bf16 && !out_ptr_override) ? storage_type(c) : 0;
+    const int out_st = out_view ? out_view->st : ((use_bf16 && !out_ptr_override) ? storage_type(c) : 0);
     if (out_st && (out_c & 7)) return fail(c, APSE_E_INVALID, "16-bit tensors need C % 8 == 0 at " + sp.name);
     Tens o;
-    if (out_ptr_override) { o.p = out_ptr_override; o.H = oh; o.W = ow; o.C = out_c; }
+    if (out_view) { o = *out_view; o.H = oh; o.W = ow; o.C = out_c; c->t[out_name] = o; }      // a slice of a larger allocation
+    else if (out_ptr_override) { o.p = out_ptr_override; o.H = oh; o.W = ow; o.C = out_c; }
     else o = make_t(c, out_name, c->cfg.max_batch * in_items_mult, oh, ow, out_c, out_st);
     p.y_st = o.st;
     if (!o.p) return fail(c, APSE_E_NOMEM, "activation alloc failed at " + sp.name);
@@ -343,7 +345,7 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
                     p.next_w_bytes = bytes > (64u << 20) ? (64u << 20) : (unsigned)bytes;
                     break;
                 }
-            p.B = batch * st.c.b_mult;
+            p.B = st.c.fixed_items > 0 ? st.c.fixed_items : batch * st.c.b_mult;
             p.M = p.B * p.OH * p.OW;
             p.ws = c->ws;
             // In-launch split-K reduction (last arriver) measured SLOWER here than the separate reduce kernel
@@ -484,19 +486,46 @@ static int build_plan(apse_ctx* c) {
     memset(&c->rl_host, 0, sizeof(c->rl_host));
     c->rl_host.head_ld = 16;
     c->rl_host.pre_topk = g.rpn_pre_topk;
+    // The 3x3 convolution runs per level; its outputs are slices of ONE buffer ([level][max_batch][H][W][256]) so that the
+    // fused 1x1 head (objectness + deltas, shared weights) is a single launch over all rows of all levels
+    // (five launches of 10-20 us, four of them with a handful of blocks, become one).
+    size_t rows_total = 0, row_off[6] = {0};
+    for (int l = 0; l < 5; ++l) { row_off[l] = rows_total; rows_total += (size_t)B * pl[l].H * pl[l].W; }
+    row_off[5] = rows_total;
+    const int rpn_st = storage_type(c);
+    Tens t_all = make_t(c, "rpn_t_all", 1, 1, (int)rows_total, 256, rpn_st);
+    if (!t_all.p) return fail(c, APSE_E_NOMEM, "rpn feature buffer");
     for (int l = 0; l < 5; ++l) {
-        char tn[32], hn[32];
+        char tn[32];
         snprintf(tn, sizeof tn, "rpn_t%d", l + 2);
-        snprintf(hn, sizeof hn, "rpn_head%d", l + 2);
-        Tens tt, hh;
+        Tens view = t_all;
+        view.p = reinterpret_cast<float*>(reinterpret_cast<char*>(t_all.p) + row_off[l] * 256 * (rpn_st ? 2 : 4));
+        Tens tt;
         rc = add_conv(c, c->rpnhead, ConvSpec{tn, {"proposal_generator.rpn_head.conv"}, 3, 3, 1, 1, 1}, pl[l], 1, &tt, tn, nullptr,
-                      0, 0, 0);
+                      0, 0, 0, nullptr, &view);
         if (rc) return rc;
+    }
+    Tens h_all;
+    {
+        Tens in_all = t_all;                       // [1][rows_total][256] as one 1 x rows image
+        float* hbuf = dalloc<float>(c, rows_total * 16);
+        if (!hbuf) return fail(c, APSE_E_NOMEM, "rpn head buffer");
         rc = add_conv(c, c->rpnhead,
-                      ConvSpec{hn, {"proposal_generator.rpn_head.objectness_logits", "proposal_generator.rpn_head.anchor_deltas"},
+                      ConvSpec{"rpn_head_all", {"proposal_generator.rpn_head.objectness_logits", "proposal_generator.rpn_head.anchor_deltas"},
                                1, 1, 1, 0, 0},
-                      tt, 1, &hh, hn, nullptr, 0, 16, 0);
+                      in_all, 1, &h_all, "rpn_head_all", nullptr, 0, 16, 0, hbuf);
         if (rc) return rc;
+        ConvStep& hs = c->rpnhead.back().c;
+        hs.fixed_items = 1;                        // all rows of all levels, whatever the batch of this forward
+        hs.flops_per_item /= (double)B;            // profile accounting is per image
+    }
+    for (int l = 0; l < 5; ++l) {
+        char hn[32];
+        snprintf(hn, sizeof hn, "rpn_head%d", l + 2);
+        Tens hh = h_all;
+        hh.p = h_all.p + row_off[l] * 16;
+        hh.H = pl[l].H; hh.W = pl[l].W; hh.C = 16;
+        c->t[hn] = hh;
         RpnLevel& L = c->rl_host.lv[l];
         L.head = hh.p; L.H = hh.H; L.W = hh.W; L.stride = strides[l];
         L.n = hh.H * hh.W * 3;

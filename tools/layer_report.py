@@ -41,9 +41,10 @@ for l in (5, 4, 3, 2):
     hh, ww, c = dims[l]
     conv('lat%d' % l, hh * ww, 256, c)
     conv('out%d' % l, hh * ww, 256, 256 * 9)
-for l, (hh, ww) in enumerate([(192, 336), (96, 168), (48, 84), (24, 42), (12, 21)]):
+rpn_levels = [(192, 336), (96, 168), (48, 84), (24, 42), (12, 21)]
+for l, (hh, ww) in enumerate(rpn_levels):
     conv('rpn_t%d' % (l + 2), hh * ww, 256, 2304)
-    conv('rpn_h%d' % (l + 2), hh * ww, 15, 256)
+conv('rpn_head', sum(hh * ww for hh, ww in rpn_levels), 15, 256)        # one launch over the rows of all levels
 conv('fc1', 1000, 1024, 12544)
 conv('fc2', 1000, 1024, 1024)
 conv('pred', 1000, 21, 1024)
