@@ -60,6 +60,7 @@ int apse_k_dense_to_bits(const uint8_t*, int, int, int, uint64_t*, unsigned long
 
 static std::string g_create_error;
 #define NMS_SLOT 1024
+#define APSE_EXPECTED_DETS 8      // list length the packed-list GEMMs are shaped for (static: see add_conv)
 
 struct HostW { std::vector<float> v; std::vector<int64_t> shape; };
 struct Tens { float* p = nullptr; int H = 0, W = 0, C = 0; int st = 0; };   // per-item NHWC dims; st: 0 f32, 1 bf16, 2 f16 storage
@@ -106,7 +107,7 @@ struct apse_ctx {
     float* emb_raw = nullptr;
     float* rf_mask = nullptr; size_t rf_mask_floats = 0;      // apse_roi_features: masks at p2 resolution (grown on demand)
     bool box_maxc_clean = false;
-    int hint_total = 8;      // detections seen in the previous forward: sizes the tiles of the packed-list GEMMs
+    int hint_total = 8;      // detections seen in the previous forward: sizes the GRID of the packed-list GEMMs, nothing else
     // per-kernel profiling with HIP events on the caller's stream (bench.py roofline)
     bool prof_on = false; std::vector<hipEvent_t> ev_pool; int ev_used = 0;
     struct Pending { int cfg; double flops_per_item; int count_kind; int b_mult; int batch; int e0, e1; };
@@ -316,8 +317,17 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     const int Mfull = c->cfg.max_batch * in_items_mult * p.OH * p.OW;
     int sk = 1;
     cs.cfg = apse_conv_pick_cfg(Mfull, Cout, p.steps_total, &sk);
+    if (count_kind == 2) {
+        // GEMMs over the packed detection list: the tile shape and the K split fix the f32 summation order, so they are
+        // chosen HERE, once, from plan constants only (a typical list of APSE_EXPECTED_DETS detections; never from
+        // max_batch, the batch of a forward or an earlier frame's count).  A frame's masks / embeddings are then the
+        // same bits whatever ran before it, in whatever batch or shard.  The live count only sizes the grid (m_hint).
+        const int kd = c->cfg.dets_per_image < APSE_EXPECTED_DETS ? c->cfg.dets_per_image : APSE_EXPECTED_DETS;
+        const int rows = kd * p.OH * p.OW;
+        sk = 1;
+        cs.cfg = apse_conv_pick_cfg(rows < Mfull ? rows : Mfull, Cout, p.steps_total, &sk);
+    }
     p.splitk = sk;
-    if (count_kind == 2 && p.steps_total >= 16 && sk < 4) sk = 4;      // room for the hint-based split of small lists
     if (sk > 1) {
         const size_t need = (size_t)sk * Mfull * Cout;
         if (need > c->ws_floats) c->ws_floats = need;
@@ -356,14 +366,10 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
             int cfg = st.c.cfg;
             if (st.c.count_kind == 2) {
                 p.m_count = total_dev;
-                // tile / split-K choice from the expected row count (any choice is correct for any count)
+                // the previous forward's count sizes the GRID only (blocks are persistent over the live tiles, so any
+                // grid computes every tile the same way); tile shape and K split are plan constants (add_conv)
                 const int mh = (c->hint_total > 0 ? c->hint_total : 1) * p.m_per_item;
-                int sk = 1;
-                cfg = apse_conv_pick_cfg(mh < p.M ? mh : p.M, p.Cout, p.steps_total, &sk);
                 p.m_hint = mh < p.M ? mh : p.M;
-                const size_t cap = c->ws_floats / ((size_t)p.M * p.Cout);
-                if ((size_t)sk > cap) sk = (int)cap;
-                p.splitk = sk < 1 ? 1 : sk;
             }
             else if (st.c.count_kind == 1 && batch == 1) p.m_count = propcnt_dev;
             int e0 = -1;

@@ -92,3 +92,51 @@ def gather_records(records, rank, world, device, kd=100, edim=128, unpack=True):
         for i in range(counts[r]):
             res.append(unpack_record(h[r, i], kd, edim))
     return res
+
+
+def spawn_local_ranks(script, argv, n, extra_env=None):
+    """Starts ``n`` rank processes of ``script`` on this node (one per GPU) and returns the job's exit code.
+
+    For ``bench.py --gpus N`` / ``tools/run_sequence.py --gpus N`` started WITHOUT a launcher (no WORLD_SIZE in the
+    environment).  Plain child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, the
+    rendezvous on 127.0.0.1; the calling process must not have touched the GPU (it only relays: rank 0's stdout is
+    passed through line by line, the other ranks' stdout goes to stderr).  Any rank failing ends the job: the
+    remaining children are terminated (by pid) and the first non-zero exit code is returned."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import time
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    def relay():
+        for line in procs[0].stdout:             # ends when rank 0 closes its stdout (exit)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    import threading
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:                # a dead rank leaves the others blocked in a collective
+                    q.terminate()
+        time.sleep(0.05)
+    th.join(timeout=5)
+    return rc

@@ -66,14 +66,34 @@ def main():
                     help="f32 = exact-f32 MFMA (reference numerics, BASELINE configs[1]); bf16 = bf16 matrix cores with "
                          "f32 accumulate/storage for the bulk GEMMs (configs[2]/[4] style)")
     ap.add_argument("--bg-bias", type=float, default=None)
+    ap.add_argument("--rehearse-spawn", action="store_true",
+                    help="no GPU work: rendezvous, the record gather and the max-over-ranks timing only (CPU test of the "
+                         "--gpus N launch path; use with APSE_DIST_BACKEND=gloo)")
     args = ap.parse_args()
 
+    # ---- N ranks: one process per GPU.  Under a launcher (torchrun: WORLD_SIZE set) this process IS a rank; without one
+    # `--gpus N` starts the N ranks itself -- before anything touches the GPU -- and only relays rank 0's JSON line.
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from apse_uav_amd.sharding import spawn_local_ranks
+        sys.exit(spawn_local_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    ndev = max(torch.cuda.device_count(), 1)
-    dev_index = local_rank % ndev            # rehearsals may put several ranks on one GPU (APSE_DIST_BACKEND=gloo)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; pass --gpus %d (the reported n_gpus "
+                 "must be the number of ranks that ran)" % (args.gpus, world, world))
     backend = os.environ.get("APSE_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+    if args.rehearse_spawn:
+        return rehearse_spawn(args, rank, world, backend)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no GPU visible (the apse_uav hot path has no CPU fallback)")
+    if backend == "nccl" and world > ndev:
+        sys.exit("bench.py: --gpus %d needs %d GPUs on this node, %d visible (a one-GPU rehearsal of the launch path: "
+                 "APSE_DIST_BACKEND=gloo)" % (world, world, ndev))
+    dev_index = local_rank % ndev            # rehearsals may put several ranks on one GPU (APSE_DIST_BACKEND=gloo)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -277,6 +297,48 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd, asd, host_frames, blocks, H, W, args.cpu_frames, args.cpu_threads)
         print(json.dumps(out))
     if dist is not None:
+        dist.destroy_process_group()
+
+
+def rehearse_spawn(args, rank, world, backend):
+    """The multi-rank skeleton of main() without GPU work: rendezvous on MASTER_ADDR/PORT, barrier, `steps` synthetic
+    per-frame records per rank, the ONE gather + rank-0 replay, max-over-ranks timing, one JSON line from rank 0."""
+    import torch.distributed as dist
+    from apse_uav_amd.sharding import gather_records
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1 and backend == "nccl":
+        sys.exit("bench.py --rehearse-spawn runs without a GPU: set APSE_DIST_BACKEND=gloo")
+    if os.environ.get("APSE_REHEARSE_FAIL_RANK") == str(rank):
+        sys.exit(3)                              # tests: a rank that dies must end the whole job with a non-zero code
+    if world > 1:
+        dist.init_process_group(backend)
+        dist.barrier()
+    t0 = time.perf_counter()
+    rng = np.random.RandomState(rank)
+    recs = []
+    for i in range(args.steps):
+        n = 3
+        e = rng.randn(n, 128).astype(np.float32)
+        recs.append(dict(boxes=rng.rand(n, 4).astype(np.float32), scores=rng.rand(n).astype(np.float32),
+                         classes=np.zeros(n, np.int64), centroids=rng.randint(1, 2000, (n, 2)).astype(np.int32),
+                         mass=np.full(n, 10, np.int32), rects=np.zeros((n, 4), np.int32),
+                         closest=rng.randint(1, 2000, (n, n, 2)).astype(np.int32),
+                         embeddings=e / np.linalg.norm(e, axis=1, keepdims=True)))
+    frames_seen = len(recs)
+    if world > 1:
+        got = gather_records(recs, rank, world, torch.device("cpu"))
+        frames_seen = len(got) if rank == 0 else 0
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        print(json.dumps({"metric": "4K UAV frames/sec (whole node)", "value": None, "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "rehearsal": True, "records_gathered": frames_seen,
+                          "ms_per_step": round(1000.0 * elapsed / max(args.steps, 1), 3)}))
+    if world > 1:
         dist.destroy_process_group()
 
 

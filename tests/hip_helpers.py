@@ -61,3 +61,45 @@ def err_stats(a, b):
     diff = (a - b).abs()
     scale = b.abs().max().clamp_min(1e-30)
     return dict(max_abs=float(diff.max()), rel_to_max=float(diff.max() / scale), nan=int(torch.isnan(a).sum()))
+
+
+def _live_bytes(model, res):
+    """Every live byte a frame produces: the record of image 0 (boxes, scores, classes, centroids, mass, rects,
+    closest-point table, embeddings), the raw embeddings, the mask logits and the bit planes of its mask windows."""
+    rec = res.record(0)
+    parts = [np.ascontiguousarray(rec[k]).tobytes() for k in
+             ("boxes", "scores", "classes", "centroids", "mass", "rects", "closest", "embeddings", "packed_index")]
+    inst = model.instances_from(res, 0, want_masks=True)
+    for m in inst.pred_masks:
+        if m.bits is not None:
+            parts.append(m.bits.cpu().numpy().tobytes())
+    n = len(rec["scores"])
+    logits = model.debug_tensor("mask_logits").cpu().numpy().reshape(-1)[: n * 28 * 28 * 4]
+    parts.append(logits.tobytes())
+    parts.append(model.debug_tensor("embedding_raw").cpu().numpy().reshape(-1)[: n * 128].tobytes())
+    return n, b"".join(parts)
+
+
+def history_independence(tracker, frame_a, image_hw, rng_seed=0):
+    """Frame A after forwards that left 0, 8 and 100 detections in the packed list must give the same BYTES: the
+    tile shape / K split of the count-limited GEMMs (mask head, deconv, mask logits, association FC) are plan
+    constants, the previous count only sizes their grid (csrc/detector.hip add_conv / run_plan)."""
+    pr = tracker.predictor
+    model = pr.model
+    dev = pr._upload([frame_a])
+    rng = np.random.RandomState(rng_seed)
+    ih, iw = image_hw
+    outs = []
+    for prev in (0, 8, 100):
+        x0 = rng.uniform(0, iw - 60, prev)
+        y0 = rng.uniform(0, ih - 60, prev)
+        boxes = np.stack([x0, y0, x0 + rng.uniform(8, 56, prev), y0 + rng.uniform(8, 56, prev)], 1).astype(np.float32)
+        given = (boxes.reshape(-1, 4), np.zeros(prev, np.int32), np.array([prev], np.int32))
+        model.preprocess_frames(dev)
+        model.run(1, given)
+        assert model.read(1).total == prev                 # the count the next forward sees as its hint
+        model.preprocess_frames(dev)
+        model.run(1)
+        outs.append(_live_bytes(model, model.read(1)))
+    return outs
+

@@ -345,3 +345,13 @@ def test_config3_like_batch4_bf16_with_preproc(setup, logdir, golden_dir):
                 matched += 1
     _log(logdir, "config3", dict(dets=tot, matched=matched))
     assert matched >= int(0.95 * tot)              # 16-bit noise floor flips a few near-threshold candidates
+
+
+def test_results_independent_of_history(setup, logdir):
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from hip_helpers import history_independence
+    tr = RcnnTracker(_cfg(), FRAME, setup["asd"], detector_state=setup["sd"])
+    outs = history_independence(tr, setup["seq"].frame(0), (setup["ih"], setup["iw"]))
+    _log(logdir, "history", dict(n=[o[0] for o in outs], nbytes=[len(o[1]) for o in outs]))
+    assert outs[0][0] > 0
+    assert outs[0][1] == outs[1][1] == outs[2][1]

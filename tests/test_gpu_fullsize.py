@@ -206,3 +206,56 @@ def test_full_frame_16bit_vs_oracle(env, logdir, dtype):
     _log(logdir, dtype + "/dets", dict(n=n, ref_n=rn, matched=matched, scores=[round(float(s), 4) for s in inst.scores],
                                        ref=[round(float(s), 4) for s in post["scores"]]))
     assert abs(n - rn) <= 2 and matched >= min(n, rn) - 2
+
+
+def test_4k_results_independent_of_history(env, logdir):
+    """R-101 at 3840x2160: frame A after 0-, 8- and 100-detection forwards -> identical bytes (hip_helpers)."""
+    from apse_uav_amd.utils import resample
+    from hip_helpers import history_independence
+    outs = history_independence(env["tr"], env["seq"].frame(0), resample.resize_shortest_edge(*FRAME))
+    _log(logdir, "history4k", dict(n=[o[0] for o in outs], nbytes=[len(o[1]) for o in outs]))
+    assert outs[0][0] > 0
+    assert outs[0][1] == outs[1][1] == outs[2][1]
+
+
+def test_4k_shards_and_pipeline_equal_sequential(env, logdir):
+    """"single ordered CSV identical to the 1-GPU run".  Six 4K frames through (a) RcnnTracker.next_frame,
+    (b) two independent shards [0,3) / [3,6) (fresh contexts, as two ranks would hold) -> wire format -> replay,
+    (c) PipelinedRcnnTracker(depth=3): the CSV text must be equal byte for byte, the records bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_sequence as rs
+    from apse_uav_amd.engines.pipelined_tracker import PipelinedRcnnTracker
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from apse_uav_amd.sharding import pack_record, shard_frames, unpack_record
+    cfg = env["cfg"].clone()
+    cfg.APSE.MAX_BATCH = 1
+    n = 6
+    frames = [env["seq"].frame(7 * t) for t in range(n)]          # the dynamic sequence moves: detections differ per frame
+    seq_tr = RcnnTracker(cfg, FRAME, env["asd"], detector_state=env["sd"])
+    ref_lines, ref_recs = [], []
+    for t in range(n):
+        objs = seq_tr.next_frame(frames[t])
+        ref_lines.append(seq_tr.log_line(objs, 1, t)[0])
+        ref_recs.append(pack_record(seq_tr._last_record, 100, 128).tobytes())
+    del seq_tr
+    recs = []
+    for rank in range(2):
+        lo, hi = shard_frames(n, rank, 2)
+        w = RcnnTracker(cfg, FRAME, env["asd"], detector_state=env["sd"])
+        recs += [pack_record(r, 100, 128) for r in rs.detect_range(w, lambda k: frames[k], lo, hi, 1)]
+        del w
+    same_recs = sum(a.tobytes() == b for a, b in zip(recs, ref_recs))
+    rep = RcnnTracker(cfg, FRAME, env["asd"], detector_state=env["sd"])
+    lines, _ = rs.replay(rep, [unpack_record(r, 100, 128) for r in recs], 1)
+    lines_native, _ = rs.replay(rep, [unpack_record(r, 100, 128) for r in recs], 1, fast=True)
+    del rep
+    drv = PipelinedRcnnTracker(cfg, FRAME, env["asd"], depth=3, detector_state=env["sd"])
+    plines = [drv.tracker.log_line(objs, 1, t)[0] for t, objs in drv.run(frames)]
+    _log(logdir, "shards4k", dict(records_equal=same_recs, sharded_lines_equal=sum(a == b for a, b in zip(lines, ref_lines)),
+                                  pipelined_lines_equal=sum(a == b for a, b in zip(plines, ref_lines)), n=n,
+                                  sample=ref_lines[-1][:100]))
+    assert any(ref_lines)
+    assert same_recs == n
+    assert lines == ref_lines and lines_native == ref_lines
+    assert plines == ref_lines

@@ -72,3 +72,37 @@ def test_pack_unpack_roundtrip_and_shards():
         lo, hi = shard_frames(2734, rank, 8)
         cover += list(range(lo, hi))
     assert cover == list(range(2734))
+
+
+def _bench(args, env_extra, timeout=180):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, lines, p.stderr
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` without a launcher must run TWO ranks and say n_gpus 2 in rank 0's single JSON line
+    (the GPU-free --rehearse-spawn body: same rendezvous / gather / max-over-ranks timing as the real run)."""
+    rc, lines, err = _bench(["--gpus", "2", "--steps", "3", "--rehearse-spawn"], {"APSE_DIST_BACKEND": "gloo"})
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["records_gathered"] == 6 and lines[0]["steps"] == 3
+
+
+def test_bench_gpus_flag_must_match_the_launcher():
+    rc, lines, err = _bench(["--gpus", "4", "--rehearse-spawn"], {"WORLD_SIZE": "2", "RANK": "0", "APSE_DIST_BACKEND": "gloo"})
+    assert rc != 0 and not lines and "WORLD_SIZE=2" in err
+    rc, lines, err = _bench(["--rehearse-spawn"], {"WORLD_SIZE": "2", "RANK": "0", "APSE_DIST_BACKEND": "gloo"})
+    assert rc != 0 and not lines           # torchrun with 2 ranks but --gpus left at 1: refuse, never print n_gpus 1
+
+
+def test_bench_a_dead_rank_fails_the_job():
+    rc, lines, err = _bench(["--gpus", "2", "--steps", "2", "--rehearse-spawn"],
+                            {"APSE_DIST_BACKEND": "gloo", "APSE_REHEARSE_FAIL_RANK": "1"})
+    assert rc != 0 and not lines
