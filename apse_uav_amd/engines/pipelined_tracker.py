@@ -22,6 +22,7 @@ import torch
 
 from ..networks.track_rcnn import TrackRCNN
 from .rcnn_tracker import RcnnTracker, instances_from_record
+from .track_predictor import FrameUploader
 
 
 class PipelinedRcnnTracker:
@@ -40,28 +41,31 @@ class PipelinedRcnnTracker:
             m.attach_association_head(self.tracker.association_head)
             self.models.append(m)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
-        self._staging = [None] * depth
+        self._uploader = FrameUploader(self.device, self.tracker.predictor.input_format, nslots=depth + 1)
         self._inflight = collections.deque()
         self._submitted = 0
 
     # ------------------------------------------------------------------ one frame in, zero or one out
     def submit(self, frame):
-        """Enqueues a frame (HxWx3 uint8 BGR ndarray, or a uint8 CUDA tensor [H, W, 3]) on the next slot.
-        Call ``collect`` first when ``depth`` frames are already in flight."""
+        """Enqueues a frame (HxWx3 uint8 ndarray in cfg.INPUT.FORMAT order, or a uint8 BGR CUDA tensor [H, W, 3]) on
+        the next slot.  Call ``collect`` first when ``depth`` frames are already in flight."""
         assert len(self._inflight) < self.depth, "collect() before submitting more than depth frames"
         k = self._submitted % self.depth
-        with torch.cuda.stream(self.streams[k]):
-            if torch.is_tensor(frame):
-                dev = frame.reshape((1,) + tuple(frame.shape[-3:]))
-            else:
-                H, W = frame.shape[:2]
-                if self._staging[k] is None or self._staging[k].shape != (1, H, W, 3):
-                    self._staging[k] = torch.empty((1, H, W, 3), dtype=torch.uint8).pin_memory()
-                self._staging[k][0].copy_(torch.from_numpy(np.ascontiguousarray(frame)))
-                dev = self._staging[k].to(self.device, non_blocking=True)
-                if self.tracker.predictor.frame_preprocessor is not None:
-                    dev = self.tracker.predictor.frame_preprocessor(dev)
+        st = self.streams[k]
+        slot = None
+        if torch.is_tensor(frame):
+            dev = frame.reshape((1,) + tuple(frame.shape[-3:]))
+            st.wait_stream(torch.cuda.current_stream(self.device))     # whatever produced the tensor
+            dev.record_stream(st)                                      # the allocator must not recycle it under us
+        else:
+            slot = self._uploader.begin([frame], st)                   # same staging / channel-order logic as TrackPredictor
+            dev = slot.dev
+        with torch.cuda.stream(st):
+            if self.tracker.predictor.frame_preprocessor is not None:
+                dev = self.tracker.predictor.frame_preprocessor(dev)
             self.models[k].preprocess_frames(dev)
+            if slot is not None:
+                FrameUploader.release(slot, st)
             self.models[k].run(1)
         self._inflight.append((self._submitted, k))
         self._submitted += 1

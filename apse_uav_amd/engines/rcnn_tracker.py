@@ -62,10 +62,12 @@ class RcnnTracker:
         self._obj_det = {}
 
     # ------------------------------------------------------------------ per frame
-    def next_frame(self, frame):
+    def next_frame(self, frame, upcoming=None):
+        """``upcoming`` (build extension, optional): the frame the NEXT call will be given; its host copy + H2D then
+        overlap this frame's GPU work (TrackPredictor.prefetch).  Results do not depend on it."""
         self.frame_count += 1
         if 'frame_count' in self.DISPLAY_INFO: print("\nFRAME: ", self.frame_count)
-        detections, backbone_features = self.predictor(frame)
+        detections, backbone_features = self.predictor(frame, upcoming=upcoming)
         detections = detections['instances']
         return self._finish_frame(detections, backbone_features)
 

@@ -6,6 +6,11 @@ reference resizes on the CPU with PIL and uploads a 12 MB f32 image; here the u8
 once (24.9 MB at 4K) and the PIL-exact resize, normalisation and padding run as HIP kernels.
 Weights: ``cfg.MODEL.WEIGHTS`` (a ``.pth`` with key "model" or a bare state_dict) or
 ``load_state_dict``.
+
+Ingest (the reference loop is dcnn/scripts/tests/visualize_uav.py:172-190): frames go
+through ``FrameUploader`` -- two pinned staging buffers, two device buffers and a copy stream.  ``prefetch(frame)``
+starts the host copy + H2D of the NEXT frame while the current one computes; ``predictor(frame)`` then finds it
+resident.  Without a prefetch the same buffers are used on the calling stream.
 """
 import numpy as np
 import torch
@@ -14,10 +19,70 @@ from ..networks.track_rcnn import TrackRCNN
 from ..weights import load_detector_file
 
 
+class _Slot:
+    __slots__ = ("pinned", "dev", "h2d_done", "consumed", "consumed_pending", "key")
+
+    def __init__(self, shape, device):
+        self.pinned = torch.empty(shape, dtype=torch.uint8).pin_memory()
+        self.dev = torch.empty(shape, dtype=torch.uint8, device=device)
+        self.h2d_done = torch.cuda.Event()
+        self.consumed = torch.cuda.Event()
+        self.consumed_pending = False        # True: handed out, the consumer's event has not been recorded yet
+        self.key = None
+
+
+class FrameUploader:
+    """Host frames -> device, double-buffered.  ``begin(frames, stream)`` stages ``frames`` (list of HxWx3 uint8
+    arrays) into the next slot's pinned buffer and enqueues the H2D on ``stream``; the slot's device buffer is
+    overwritten only after its previous consumer has run (``consumed`` event, recorded by ``release``)."""
+
+    def __init__(self, device, input_format="BGR", nslots=2):
+        self.device = torch.device(device)
+        self.input_format = input_format
+        self.nslots = max(2, int(nslots))
+        self._slots = [None] * self.nslots
+        self._k = -1
+
+    def begin(self, frames, stream):
+        B = len(frames)
+        H, W = frames[0].shape[:2]
+        shape = (B, H, W, 3)
+        self._k = (self._k + 1) % self.nslots
+        sl = self._slots[self._k]
+        if sl is None or tuple(sl.pinned.shape) != shape:
+            sl = self._slots[self._k] = _Slot(shape, self.device)
+        else:
+            sl.h2d_done.synchronize()                 # the pinned buffer's previous H2D has left the host
+        for i, f in enumerate(frames):
+            if f.shape[:2] != (H, W):
+                raise ValueError("frames of one batch must have the same size")
+            if self.input_format == "RGB":            # track_predictor.py:43-45: the model wants BGR
+                f = f[:, :, ::-1]
+            sl.pinned[i].copy_(torch.from_numpy(np.ascontiguousarray(f)))
+        if sl.consumed_pending:                       # a caller that never released the slot: be conservative
+            sl.consumed.record(torch.cuda.current_stream(self.device))
+            sl.consumed_pending = False
+        with torch.cuda.stream(stream):
+            stream.wait_event(sl.consumed)            # device buffer: its last reader (the resize kernels) is done
+            sl.dev.copy_(sl.pinned, non_blocking=True)
+            sl.h2d_done.record(stream)
+        sl.key = list(frames)                        # references, so identity stays meaningful until the slot is reused
+        sl.consumed_pending = True
+        return sl
+
+    @staticmethod
+    def release(sl, stream=None):
+        """Call after the last kernel reading ``sl.dev`` has been enqueued on ``stream`` (default: current)."""
+        sl.consumed.record(stream if stream is not None else torch.cuda.current_stream(sl.dev.device))
+        sl.consumed_pending = False
+
+
 class TrackPredictor:
+    model_class = TrackRCNN
+
     def __init__(self, cfg, state_dict=None):
         self.cfg = cfg.clone()
-        self.model = TrackRCNN(self.cfg)
+        self.model = self.model_class(self.cfg)
         self.model.to(torch.device(cfg.MODEL.DEVICE))
         self.model.eval()
         if state_dict is not None:
@@ -26,38 +91,78 @@ class TrackPredictor:
             self.model.load_state_dict(load_detector_file(cfg.MODEL.WEIGHTS))
         self.input_format = cfg.INPUT.FORMAT
         assert self.input_format in ["RGB", "BGR"], self.input_format
-        self._staging = None
         self.frame_preprocessor = None        # optional FramePreprocessor (cfg.APSE.FUSED_PREPROC / set_camera)
+        self._uploader = None
+        self._copy_stream = None
+        self._prefetched = None
+        self._last_slot = None
 
     def set_camera(self, cam_params, gamma=2.0):
         """Enables undistort + Lab-gamma in front of the resize (preprocess_img, visualize_uav.py:56-71)."""
         from ..utils.preprocess import FramePreprocessor
         self.frame_preprocessor = FramePreprocessor(cam_params, gamma)
 
+    # ------------------------------------------------------------------ ingest
+    def _up(self):
+        if self._uploader is None:
+            if self.model.device.type != "cuda" or not torch.cuda.is_available():
+                from .._lib import ApseError
+                raise ApseError("the apse_uav hot path needs a ROCm GPU (cfg.MODEL.DEVICE=%s): no CPU fallback" % self.model.device)
+            self._uploader = FrameUploader(self.model.device, self.input_format)
+            self._copy_stream = torch.cuda.Stream(device=self.model.device)
+        return self._uploader
+
+    def prefetch(self, frames):
+        """Starts the upload of the frame(s) the NEXT call will be given (an HxWx3 array or a list of them) on the
+        copy stream, so the 24.9 MB H2D overlaps the GPU work already enqueued.  The next call must pass the SAME array
+        object(s); anything else is uploaded afresh."""
+        if frames is None:
+            return
+        frames = list(frames) if isinstance(frames, (list, tuple)) else [frames]
+        self._prefetched = self._up().begin(frames, self._copy_stream)
+
     def _upload(self, frames):
-        """list of HxWx3 uint8 arrays -> CUDA tensor [B, H, W, 3] through a pinned staging buffer."""
-        B = len(frames)
-        H, W = frames[0].shape[:2]
-        if self._staging is None or self._staging.shape != (B, H, W, 3):
-            self._staging = torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory()
-        for i, f in enumerate(frames):
-            if self.input_format == "RGB":
-                f = f[:, :, ::-1]
-            self._staging[i].copy_(torch.from_numpy(np.ascontiguousarray(f)))
-        dev = self._staging.to(self.model.device, non_blocking=True)
+        """list of HxWx3 uint8 arrays -> CUDA tensor [B, H, W, 3] (BGR), resident or in flight on the current stream."""
+        up = self._up()
+        cur = torch.cuda.current_stream(self.model.device)
+        sl, self._prefetched = self._prefetched, None
+        if sl is not None and len(sl.key) == len(frames) and all(a is b for a, b in zip(sl.key, frames)):
+            cur.wait_event(sl.h2d_done)
+        else:
+            if sl is not None:
+                FrameUploader.release(sl, self._copy_stream)          # a prefetch that was never used
+            sl = up.begin(frames, cur)
+        self._last_slot = sl
+        dev = sl.dev
         if self.frame_preprocessor is not None:
             dev = self.frame_preprocessor(dev)
+            FrameUploader.release(sl)
         return dev
 
-    def __call__(self, original_image):
+    def _frames_consumed(self):
+        """The resize kernels reading the uploaded frame are enqueued: its device buffer may be refilled after them."""
+        if self._last_slot is not None and self._last_slot.consumed_pending:
+            FrameUploader.release(self._last_slot)
+
+    # ------------------------------------------------------------------ inference
+    def _predict(self, frames, given=None, want_masks=True, upcoming=None, rpn_levels=31):
+        model = self.model
+        dev = self._upload(frames)
+        B = model.preprocess_frames(dev)
+        self._frames_consumed()
+        model.run(B, given, rpn_levels)
+        self.prefetch(upcoming)               # host copy + H2D of the next frame while this one computes
+        res = model.read(B)
+        from ..networks.track_rcnn import LazyFeatures
+        return [model.instances_from(res, b, want_masks) for b in range(B)], LazyFeatures(model, B)
+
+    def __call__(self, original_image, upcoming=None):
         with torch.no_grad():
-            dev = self._upload([original_image])
-            insts, feats = self.model.inference_frames(dev)
+            insts, feats = self._predict([original_image], upcoming=upcoming)
             return {"instances": insts[0]}, feats
 
-    def predict_batch(self, frames, given=None, want_masks=True):
+    def predict_batch(self, frames, given=None, want_masks=True, upcoming=None):
         """Build extension (reference is batch 1): several frames in one forward."""
         with torch.no_grad():
-            dev = self._upload(frames)
-            insts, feats = self.model.inference_frames(dev, given=given, want_masks=want_masks)
+            insts, feats = self._predict(list(frames), given=given, want_masks=want_masks, upcoming=upcoming)
             return [{"instances": i} for i in insts], feats

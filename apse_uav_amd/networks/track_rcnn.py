@@ -284,11 +284,9 @@ class TrackRCNN:
         inst._record = rec
         return inst
 
-    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):
-        """Same contract as track_rcnn.py:16-58: ``batched_inputs`` = list of
-        {"image": f32 CHW tensor (resized, BGR), "height", "width"}; returns
-        (list of {"instances": Instances}, feature dict).  ``detected_instances``: list of Instances
-        with ``pred_boxes`` (resized-image pixels) and ``pred_classes`` -> box branch skipped."""
+    def _inference_images(self, batched_inputs, detected_instances, do_postprocess, rpn_levels):
+        """Shared body of ``inference`` (track_rcnn.py:16-58) and ``SelectiveMaskRCNN.scan`` (selective_rcnn.py:27-84):
+        the reference's model input -- resized f32 CHW images -- through normalise + pad and the whole launch sequence."""
         assert not self.training
         if not do_postprocess:
             raise NotImplementedError("do_postprocess=False is not on the CSV path and is not provided")
@@ -298,13 +296,21 @@ class TrackRCNN:
         self.preprocess_images(imgs, frame_hw)
         given = None
         if detected_instances is not None:
+            assert len(detected_instances) == B
             boxes = np.concatenate([d.pred_boxes.tensor.cpu().numpy().reshape(-1, 4) for d in detected_instances])
             classes = np.concatenate([np.asarray(d.pred_classes.cpu()).reshape(-1) for d in detected_instances])
             counts = np.asarray([len(d) for d in detected_instances], np.int32)
             given = (boxes, classes, counts)
-        self.run(B, given)
+        self.run(B, given, rpn_levels)
         res = self.read(B)
-        out = [{"instances": self.instances_from(res, b)} for b in range(B)]
+        return [{"instances": self.instances_from(res, b)} for b in range(B)], B
+
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):
+        """Same contract as track_rcnn.py:16-58: ``batched_inputs`` = list of
+        {"image": f32 CHW tensor (resized, BGR), "height", "width"}; returns
+        (list of {"instances": Instances}, feature dict).  ``detected_instances``: list of Instances
+        with ``pred_boxes`` (resized-image pixels) and ``pred_classes`` -> box branch skipped."""
+        out, B = self._inference_images(batched_inputs, detected_instances, do_postprocess, 31)
         return out, LazyFeatures(self, B)
 
     def inference_frames(self, frames, given=None, want_masks=True, rpn_levels=31):

@@ -66,6 +66,8 @@ def main():
                     help="f32 = exact-f32 MFMA (reference numerics, BASELINE configs[1]); bf16 = bf16 matrix cores with "
                          "f32 accumulate/storage for the bulk GEMMs (configs[2]/[4] style)")
     ap.add_argument("--bg-bias", type=float, default=None)
+    ap.add_argument("--no-entrypoint", action="store_true", help="skip the RcnnTracker.next_frame(np.ndarray) measurement")
+    ap.add_argument("--entry-steps", type=int, default=24)
     ap.add_argument("--rehearse-spawn", action="store_true",
                     help="no GPU work: rendezvous, the record gather and the max-over-ranks timing only (CPU test of the "
                          "--gpus N launch path; use with APSE_DIST_BACKEND=gloo)")
@@ -262,13 +264,18 @@ def main():
         # the committed summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same workload
         # (tools/gpu_profile_round.sh; read side doubled per the gfx950 note of MI355X_MICROARCH.md)
         traffic, traffic_src = None, None
+        build = lib.apse_version().decode()
         if args.dtype == "f32" and B == 1 and os.path.exists(PMC_TRAFFIC_FILE):
             try:
                 with open(PMC_TRAFFIC_FILE) as fh:
-                    pm = json.load(fh).get("conv_igemm_f32" + CFG_TEMPLATE[dom])
-                if pm:
+                    pmj = json.load(fh)
+                pm = pmj.get("conv_igemm_f32" + CFG_TEMPLATE[dom])
+                if pmj.get("__build__") != build:
+                    traffic_src = ("null: profiles/pmc_traffic_latest.json was recorded for build '%s', the loaded library is "
+                                   "'%s' (re-run tools/gpu_profile_round.sh)" % (pmj.get("__build__"), build))
+                elif pm:
                     traffic = int(pm["fetch_bytes"] + pm["write_bytes"])
-                    traffic_src = "profiles/pmc_traffic_latest.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, bytes per launch"
+                    traffic_src = "profiles/pmc_traffic_latest.json (same build): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, bytes per launch"
             except (OSError, ValueError, KeyError):
                 pass
         flops_frame = model.flops(1, P_sum / max(args.steps * B, 1), N_sum / max(args.steps * B, 1))
@@ -293,6 +300,10 @@ def main():
         }
         if world == 1 and depth == 1 and args.throughput_depth > 1 and not args.from_host:
             out["throughput_mode"] = throughput_mode(cfg, sd, tracker, model, frames, nres, B, args.throughput_depth, replay)
+        out["build"] = build
+        out["association"] = "C++ Hungarian + track store of csrc/replay.hip (NativeReplay; equal to scipy linear_sum_assignment on the tests' streams)"
+        if world == 1 and depth == 1 and B == 1 and not args.no_entrypoint:
+            out["entrypoint"] = entrypoint_mode(tracker, host_frames, args.entry_steps)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, asd, host_frames, blocks, H, W, args.cpu_frames, args.cpu_threads)
         print(json.dumps(out))
@@ -383,35 +394,77 @@ def throughput_mode(cfg, sd, tracker, model, frames, nres, B, depth, replay, ste
             "engine": "PipelinedRcnnTracker"}
 
 
+def entrypoint_mode(tracker, host_frames, steps, warmup=3):
+    """The entry north_star names: ``RcnnTracker.next_frame(frame: np.ndarray HxWx3 u8 BGR)`` from HOST memory, engine
+    defaults (mask windows copied out, scipy Hungarian, track store): per frame a 24.9 MB staging copy + H2D over PCIe,
+    the GPU path, one apse_copy_mask_window per detection.  Two figures: the plain reference loop
+    (visualize_uav.py:186-221), and the same loop passing the next frame as ``upcoming`` so its upload overlaps
+    (TrackPredictor.prefetch).  Informational: the headline `value` is measured on frames resident in HBM."""
+    from apse_uav_amd.utils import csv_log  # noqa: F401  (log_line)
+    n = len(host_frames)
+    out = {}
+    for name, ahead in (("next_frame", False), ("next_frame_upcoming", True)):
+        tracker.reset_tracker()
+        lat = []
+        t0 = 0.0
+        for i in range(warmup + steps):
+            if i == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            ts = time.perf_counter()
+            objs = tracker.next_frame(host_frames[i % n], upcoming=host_frames[(i + 1) % n] if ahead else None)
+            tracker.log_line(objs, 1, i)
+            if i >= warmup:
+                lat.append(time.perf_counter() - ts)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {"value": round(steps / dt, 3), "unit": "frames/s", "p50_ms_per_frame": round(1000.0 * float(np.median(lat)), 3),
+                     "steps": steps}
+    out["what"] = ("RcnnTracker.next_frame(np.ndarray) from pageable host memory incl. staging copy, H2D, mask-window copies, "
+                   "scipy association and the CSV line")
+    return out
+
+
 def cpu_baseline(sd, asd, host_frames, blocks, H, W, nframes, max_threads):
     """The CPU oracle (a port: the reference's own CPU path cannot run, detectron2 is absent) on the same
-    frames and weights: PIL resize + detector + roi_pool/embedding + tracker association + CSV line."""
+    frames and weights: PIL resize + detector + roi_pool/embedding + tracker association + CSV line.  Timed with all
+    host cores torch will use (capped by --cpu-threads) and with 8 threads (comparable with an 8-core host)."""
     from PIL import Image
     from oracle import tracker as otr
     from oracle.detector import DetectorOracle, resize_shape
-    ncores = min(torch.get_num_threads(), max_threads, os.cpu_count() or 1)
-    torch.set_num_threads(ncores)
+    avail = min(torch.get_num_threads(), os.cpu_count() or 1)
     oracle = DetectorOracle(sd, dict(depth_blocks=blocks))
     ih, iw = resize_shape(H, W)
-    otk = otr.TrackerOracle()
 
-    def one(fr, t):
-        img = np.asarray(Image.fromarray(fr).resize((iw, ih), Image.BILINEAR))
-        post = oracle.inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), H, W)
-        rois = otr.features_rois(post["features"]["p2"], post["boxes"], W)
-        emb = otr.association_head(rois, asd["fc.weight"], asd["fc.bias"])
-        rec = otk.next_frame(dict(boxes=post["boxes"], scores=post["scores"], classes=post["classes"],
-                                  masks=list(zip(post["mask_windows"], post["mask_rects"])), emb=emb))
-        otr.log_oneline(rec, 1, t)
-    with torch.no_grad():
-        one(host_frames[0], 0)
-        t0 = time.perf_counter()
-        for t in range(nframes):
-            one(host_frames[(t + 1) % len(host_frames)], t + 1)
-        dt = time.perf_counter() - t0
-    return {"value": round(nframes / dt, 4), "unit": "frames/s", "cores": ncores, "kind": "port",
-            "sample": "%d frames of the same synthetic 3840x2160 sequence after 1 warm-up, PyTorch-CPU f32 oracle "
-                      "(torch threads = %d)" % (nframes, ncores)}
+    def timed(ncores, nfr):
+        torch.set_num_threads(ncores)
+        otk = otr.TrackerOracle()
+
+        def one(fr, t):
+            img = np.asarray(Image.fromarray(fr).resize((iw, ih), Image.BILINEAR))
+            post = oracle.inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), H, W)
+            rois = otr.features_rois(post["features"]["p2"], post["boxes"], W)
+            emb = otr.association_head(rois, asd["fc.weight"], asd["fc.bias"])
+            rec = otk.next_frame(dict(boxes=post["boxes"], scores=post["scores"], classes=post["classes"],
+                                      masks=list(zip(post["mask_windows"], post["mask_rects"])), emb=emb))
+            otr.log_oneline(rec, 1, t)
+        with torch.no_grad():
+            one(host_frames[0], 0)
+            t0 = time.perf_counter()
+            for t in range(nfr):
+                one(host_frames[(t + 1) % len(host_frames)], t + 1)
+            return nfr / (time.perf_counter() - t0)
+    ncores = min(avail, max_threads)
+    fps = timed(ncores, nframes)
+    res = {"value": round(fps, 4), "unit": "frames/s", "cores": ncores, "kind": "port",
+           "sample": "%d frames of the same synthetic 3840x2160 sequence after 1 warm-up, PyTorch-CPU f32 oracle "
+                     "(torch threads = %d)" % (nframes, ncores)}
+    if ncores > 8:
+        n8 = max(2, nframes - 1)
+        res["threads_8"] = {"value": round(timed(8, n8), 4), "unit": "frames/s", "cores": 8,
+                            "sample": "%d frames after 1 warm-up, torch threads = 8" % n8}
+    torch.set_num_threads(avail)
+    return res
 
 
 if __name__ == "__main__":

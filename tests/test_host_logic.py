@@ -178,3 +178,91 @@ def test_consumer_distance_step(golden_dir):
     da, db = csv_log.calculate_distance([host], [cen], [clo], 0.8, 40.0, 44.0)
     assert abs(da - np.hypot(1911 - 192, 966 - 1380) * 0.8 / 42.0) < 1e-9
     assert abs(db - np.hypot(1911 - 365, 966 - 1338) * 0.8 / 42.0) < 1e-9 and db < da
+
+
+# ---------------------------------------------------------------- weight formats
+def test_detector_checkpoint_formats_roundtrip(tmp_path):
+    """`.pth` = {"model": state_dict, ...} (dcnn/scripts/train/finetune_uav.py:273-283) through cfg.MODEL.WEIGHTS, a
+    bare state_dict, detectron2's non-weight buffers dropped, dtypes normalised to f32; loaders are weights_only."""
+    import torch
+    from apse_uav_amd.config import setup_cfg
+    from apse_uav_amd.engines.track_predictor import TrackPredictor
+    from apse_uav_amd.weights import blocks_from_state, load_detector_file, synthetic_detector_state
+    sd = synthetic_detector_state(3, (1, 1, 1, 1))
+    extra = dict(sd)
+    extra["proposal_generator.anchor_generator.cell_anchors.0"] = torch.zeros(3, 4)     # buffers a detectron2 0.1.2 checkpoint holds
+    extra["pixel_mean"] = torch.tensor([103.53, 116.28, 123.675]).view(3, 1, 1)
+    extra["pixel_std"] = torch.ones(3, 1, 1)
+    extra["roi_heads.box_head.fc2.bias"] = extra["roi_heads.box_head.fc2.bias"].double()   # a non-f32 tensor
+    wrapped, bare = str(tmp_path / "model_final.pth"), str(tmp_path / "bare.pth")
+    torch.save({"model": extra, "iteration": 1234, "optimizer": {"state": {}}}, wrapped)
+    torch.save(extra, bare)
+    for path in (wrapped, bare):
+        got = load_detector_file(path)
+        assert set(got) == set(sd)
+        assert all(v.dtype == torch.float32 for v in got.values())
+        assert all(torch.equal(got[k], sd[k]) for k in sd)
+        assert blocks_from_state(got) == (1, 1, 1, 1)
+    cfg = setup_cfg(device="cpu")
+    cfg.MODEL.WEIGHTS = wrapped
+    pr = TrackPredictor(cfg)                                   # the constructor path the reference uses (track_predictor.py:20-25)
+    assert set(pr.model._state) == set(sd) and torch.equal(pr.model._state["backbone.fpn_output2.weight"], sd["backbone.fpn_output2.weight"])
+
+
+def test_association_checkpoint_and_tracker_ctor(tmp_path):
+    """Association head: plain state_dict {fc.weight 128x25600, fc.bias 128} (association_head.py:13), loaded from the
+    path given as RcnnTracker's `weights` argument (rcnn_tracker.py:56)."""
+    import torch
+    from apse_uav_amd.config import setup_cfg
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from apse_uav_amd.weights import load_association_file, synthetic_association_state, synthetic_detector_state
+    asd = synthetic_association_state(5)
+    path = str(tmp_path / "association_head.pth")
+    torch.save(asd, path)
+    got = load_association_file(path)
+    assert set(got) == {"fc.weight", "fc.bias"} and got["fc.weight"].shape == (128, 25600)
+    assert all(torch.equal(got[k], asd[k]) for k in asd)
+    tr = RcnnTracker(setup_cfg(device="cpu"), (270, 480), path, detector_state=synthetic_detector_state(0, (1, 1, 1, 1)))
+    assert torch.equal(tr.association_head.fc.weight.detach().cpu(), asd["fc.weight"])
+    assert tr.predictor.model._assoc is tr.association_head
+
+
+def test_roi_features_generator_takes_backbone_only_checkpoints(tmp_path):
+    """PartialCheckpointer (dcnn/utils/partial_checkpointer.py:11-20) strips `backbone.` from every key and loads the
+    backbone alone: a stripped dict, a full dict and a `.pth` holding either must all yield the same backbone tensors."""
+    import torch
+    from apse_uav_amd.config import setup_cfg
+    from apse_uav_amd.engines.roi_features_generator import RoiFeaturesGenerator
+    from apse_uav_amd.weights import synthetic_detector_state
+    sd = synthetic_detector_state(2, (1, 1, 1, 1))
+    stripped = {k.split("backbone.")[-1]: v for k, v in sd.items() if k.startswith("backbone.")}
+    path = str(tmp_path / "backbone_only.pth")
+    torch.save({"model": stripped}, path)
+    cfg = setup_cfg(device="cpu")
+    a = RoiFeaturesGenerator(cfg, roi_size=8, state_dict=stripped).model._state
+    b = RoiFeaturesGenerator(cfg, roi_size=8, state_dict=sd).model._state
+    cfg2 = cfg.clone()
+    cfg2.MODEL.WEIGHTS = path
+    c = RoiFeaturesGenerator(cfg2, roi_size=8).model._state
+    for st in (a, b, c):
+        for k, v in sd.items():
+            if k.startswith("backbone."):
+                assert torch.equal(st[k], v), k
+            else:
+                assert k in st and st[k].shape == v.shape
+    for st in (a, b, c):                                       # heads are zero-filled: this generator never runs them
+        assert all(torch.count_nonzero(st[k]) == 0 for k in st if not k.startswith("backbone."))
+
+
+def test_model_zoo_pickle_is_refused(tmp_path):
+    """Model-zoo `.pkl` files need pickle (add_mask_head_to_frcnn.py:53-55): the loader never unpickles and says so."""
+    import pickle
+    import pytest
+    from apse_uav_amd.weights import load_detector_file
+    p = tmp_path / "model_final_a3ec72.pkl"
+    with open(p, "wb") as f:
+        pickle.dump({"model": {"backbone.bottom_up.stem.conv1.weight": np.zeros((64, 3, 7, 7), np.float32)},
+                     "__author__": "Detectron2 Model Zoo"}, f)              # numpy arrays, as the zoo files hold
+    with pytest.raises(Exception) as ei:
+        load_detector_file(str(p))
+    assert "pickle" in str(ei.value).lower() or "weights_only" in str(ei.value).lower() or "unsupported" in str(ei.value).lower()

@@ -28,6 +28,10 @@ for k in sorted(af, key=lambda k: -af[k][0]):
 # machine-readable copy for bench.py's roofline.traffic (bytes per launch, read side already doubled)
 if len(sys.argv) > 3:
     import json
-    json.dump({k.replace('void ', ''): {"launches": af[k][1], "fetch_bytes": 2 * af[k][0] / af[k][1] * 1024,
-                                        "write_bytes": aw[k][0] / max(aw[k][1], 1) * 1024} for k in af},
-              open(sys.argv[3], 'w'), indent=1)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from apse_uav_amd import _lib
+    out = {"__build__": _lib.load().apse_version().decode()}          # bench.py drops the figures when the library changed
+    out.update({k.replace('void ', ''): {"launches": af[k][1], "fetch_bytes": 2 * af[k][0] / af[k][1] * 1024,
+                                        "write_bytes": aw[k][0] / max(aw[k][1], 1) * 1024} for k in af})
+    json.dump(out, open(sys.argv[3], 'w'), indent=1)
