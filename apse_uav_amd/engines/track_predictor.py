@@ -19,11 +19,33 @@ from ..networks.track_rcnn import TrackRCNN
 from ..weights import load_detector_file
 
 
+_COPY_POOL = None
+
+
+def _host_copy(dst, src):
+    """dst[...] = src for HxWx3 uint8 arrays (25 MB at 4K) on a few plain threads (numpy releases the GIL for the copy).
+    Deliberately NOT a torch op: torch's intra-op pool (OpenMP) spins after a parallel region, and under a container CPU
+    quota those spinning workers get the whole process throttled for tens of milliseconds every few frames."""
+    global _COPY_POOL
+    n = dst.shape[0]
+    if dst.nbytes < (4 << 20) or n < 8:
+        np.copyto(dst, src)
+        return
+    if _COPY_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _COPY_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="apse-stage")
+    step = (n + 3) // 4
+    futs = [_COPY_POOL.submit(np.copyto, dst[lo:lo + step], src[lo:lo + step]) for lo in range(0, n, step)]
+    for f in futs:
+        f.result()
+
+
 class _Slot:
-    __slots__ = ("pinned", "dev", "h2d_done", "consumed", "consumed_pending", "key")
+    __slots__ = ("pinned", "pinned_np", "dev", "h2d_done", "consumed", "consumed_pending", "key")
 
     def __init__(self, shape, device):
         self.pinned = torch.empty(shape, dtype=torch.uint8).pin_memory()
+        self.pinned_np = self.pinned.numpy()
         self.dev = torch.empty(shape, dtype=torch.uint8, device=device)
         self.h2d_done = torch.cuda.Event()
         self.consumed = torch.cuda.Event()
@@ -58,7 +80,7 @@ class FrameUploader:
                 raise ValueError("frames of one batch must have the same size")
             if self.input_format == "RGB":            # track_predictor.py:43-45: the model wants BGR
                 f = f[:, :, ::-1]
-            sl.pinned[i].copy_(torch.from_numpy(np.ascontiguousarray(f)))
+            _host_copy(sl.pinned_np[i], f)            # strided source (the RGB flip) is handled by numpy
         if sl.consumed_pending:                       # a caller that never released the slot: be conservative
             sl.consumed.record(torch.cuda.current_stream(self.device))
             sl.consumed_pending = False

@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--event-every", type=int, default=8,
                     help="HIP-event pairs around every convolution launch on every n-th timed step (each pair costs "
                          "~5 us of stream time, ~1.5 ms per fully instrumented frame)")
-    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-threads", type=int, default=64, help="cap on the CPU baseline's all-cores run (further capped by the container's CPU quota)")
     ap.add_argument("--from-host", action="store_true",
                     help="frames start in pinned host memory and are uploaded inside the timed region on a copy stream "
                          "(double-buffered, overlapped with compute): the PCIe-inclusive rate noted in DESIGN.md, never "
@@ -113,6 +113,10 @@ def main():
     from apse_uav_amd import _lib
     from apse_uav_amd.config import setup_cfg
     from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from apse_uav_amd.utils.hostinfo import usable_cpus
+    # host threads: torch's intra-op pool defaults to every core it sees (256 on the GPU box) while the container's CPU
+    # quota is 16; oversubscribed, spinning OpenMP workers get the process throttled.  Size the pool by the real share.
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus() // max(world, 1) or 1)))
     from apse_uav_amd.sharding import gather_records
     from apse_uav_amd.synthetic import SyntheticSequence
     from apse_uav_amd.weights import synthetic_association_state, synthetic_detector_state
@@ -432,7 +436,8 @@ def cpu_baseline(sd, asd, host_frames, blocks, H, W, nframes, max_threads):
     from PIL import Image
     from oracle import tracker as otr
     from oracle.detector import DetectorOracle, resize_shape
-    avail = min(torch.get_num_threads(), os.cpu_count() or 1)
+    from apse_uav_amd.utils.hostinfo import usable_cpus
+    avail = usable_cpus()                                   # cgroup quota / affinity, not os.cpu_count()
     oracle = DetectorOracle(sd, dict(depth_blocks=blocks))
     ih, iw = resize_shape(H, W)
 
@@ -464,6 +469,7 @@ def cpu_baseline(sd, asd, host_frames, blocks, H, W, nframes, max_threads):
         res["threads_8"] = {"value": round(timed(8, n8), 4), "unit": "frames/s", "cores": 8,
                             "sample": "%d frames after 1 warm-up, torch threads = 8" % n8}
     torch.set_num_threads(avail)
+    res["host_cpus_usable"] = avail
     return res
 
 

@@ -289,7 +289,9 @@ class DetectorOracle:
             bf = self.box_features(feats, prop["boxes"])
             det = self.box_inference(bf["cls_logits"], bf["deltas"], prop["boxes"], image_size)
             boxes, scores, classes = det["boxes"], det["scores"], det["classes"]
+            box_det = det
         else:
+            box_det = None
             boxes = given_boxes.to(torch.float32)
             classes = given_classes.to(torch.int64)
             scores = torch.ones((boxes.shape[0],), dtype=torch.float32)
@@ -298,5 +300,6 @@ class DetectorOracle:
         post = self.postprocess(boxes, scores, classes, mh["probs"], image_size, out_h, out_w)
         post["features"] = feats
         post["proposals"] = prop
+        post["box_det"] = box_det              # pre-NMS candidates (probs, all_boxes) + kept (roi, class): threshold-margin analysis
         post["image_size"] = image_size
         return post

@@ -103,3 +103,154 @@ def history_independence(tracker, frame_a, image_hw, rng_seed=0):
         outs.append(_live_bytes(model, model.read(1)))
     return outs
 
+
+
+# ---------------------------------------------------------------------------------------------- detection-set analysis
+def _iou_matrix(a, b):
+    a, b = a.double(), b.double()
+    lt = torch.maximum(a[:, None, :2], b[None, :, :2])
+    rb = torch.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    aa = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None]
+    ab = ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None, :]
+    return inter / (aa + ab - inter).clamp(min=1e-12)
+
+
+def hip_box_side(model, b=0):
+    """Box-branch view of image ``b`` of the last forward: every (proposal, class) candidate and the kept detections,
+    in resized-image pixels -- the HIP counterpart of the oracle's ``post["box_det"]``."""
+    g = model._cfg_c
+    P, K = g.rpn_post_topk, g.num_classes
+    res = model.last_results
+    n_prop = int(res.prop_count[b])
+    allb = model.debug_tensor("cand_boxes").cpu().view(-1, P, K, 4)[b, :n_prop]
+    probs = model.debug_tensor("box_probs").cpu().view(-1, P, K + 1)[b, :n_prop]
+    lo, hi = res.image_slice(b)
+    return dict(all_boxes=allb, probs=probs, boxes=torch.from_numpy(res.box_resized[lo:hi].copy()),
+                scores=torch.from_numpy(res.score[lo:hi].copy()), classes=torch.from_numpy(res.cls[lo:hi].astype(np.int64)))
+
+
+def oracle_box_side(post):
+    d = post["box_det"]
+    return dict(all_boxes=d["all_boxes"], probs=d["probs"], boxes=d["boxes"], scores=d["scores"], classes=d["classes"])
+
+
+def _cands(side, min_score):
+    K = side["probs"].shape[1] - 1
+    s = side["probs"][:, :K].reshape(-1)
+    cls = torch.arange(K).repeat(side["probs"].shape[0])
+    keep = s > min_score
+    return side["all_boxes"].reshape(-1, 4)[keep], s[keep], cls[keep]
+
+
+def explain_detection_sets(A, B, score_thr=0.5, nms_thr=0.5, match_iou=0.9):
+    """Compares the detection sets of two runs of the box branch (HIP vs oracle, f32 vs 16-bit, ...).
+
+    Returns (report, unexplained).  Detections are paired by class and IoU >= match_iou.  The numeric noise between the
+    two runs is MEASURED on the candidates both runs score above 0.3: eps_score = max |score_A - score_B| and eps_iou =
+    max |IoU_A(i, j) - IoU_B(i, j)| over candidate pairs whose IoU lies in (0.3, 0.8).  A detection only one run keeps
+    is *explained* when the other run holds the same candidate (same class, IoU >= match_iou) and either
+      (score) that candidate's score is on the other side of score_thr and within eps_score of the kept one (eps_score
+              taken over the OTHER candidates: the disputed one does not vouch for itself), or
+      (nms)   it was suppressed there by a kept detection with IoU u > nms_thr while the same pair has IoU <= nms_thr in
+              the run that keeps it, and the two IoUs differ by at most eps_iou.
+    Anything else is returned in ``unexplained`` (a bug to find, not noise)."""
+    rep = dict(nA=int(A["boxes"].shape[0]), nB=int(B["boxes"].shape[0]))
+    ca = _cands(A, 0.3)
+    cb = _cands(B, 0.2)
+    iou = _iou_matrix(ca[0], cb[0])
+    same = ca[2][:, None] == cb[2][None, :]
+    iou_m = torch.where(same, iou, torch.zeros_like(iou))
+    best, arg = iou_m.max(dim=1) if cb[0].shape[0] else (torch.zeros(ca[0].shape[0], dtype=torch.double), None)
+    ok = best >= match_iou
+    rep["cand_pairs"] = int(ok.sum())
+    eps_s = eps_box = eps_iou = 0.0
+    pair_box = torch.zeros((0, 4))
+    pair_ds = torch.zeros((0,))
+    sub_box = torch.zeros((0, 4))
+    du = torch.zeros((0, 0), dtype=torch.double)
+    if int(ok.sum()):
+        ia = ok.nonzero()[:, 0]
+        ib = arg[ia]
+        pair_box, pair_ds = ca[0][ia], (ca[1][ia] - cb[1][ib]).abs()
+        eps_s = float(pair_ds.max())
+        eps_box = float((ca[0][ia] - cb[0][ib]).abs().max())
+        ia, ib = ia[:400], ib[:400]
+        sub_box = ca[0][ia]
+        ua, ub = _iou_matrix(sub_box, sub_box), _iou_matrix(cb[0][ib], cb[0][ib])
+        band = (ua > 0.3) & (ua < 0.8)
+        du = (ua - ub).abs() * band
+        if int(band.sum()):
+            eps_iou = float(du.max())
+    rep.update(eps_score=eps_s, eps_box_px=eps_box, eps_iou=eps_iou)
+    # pair the kept detections
+    pairs, onlyA, onlyB = [], [], list(range(rep["nB"]))
+    if rep["nA"] and rep["nB"]:
+        u = _iou_matrix(A["boxes"], B["boxes"])
+        u = torch.where(A["classes"][:, None] == B["classes"][None, :], u, torch.zeros_like(u))
+    for i in range(rep["nA"]):
+        j = int(u[i].argmax()) if rep["nB"] else -1
+        if j >= 0 and float(u[i, j]) >= match_iou and j in onlyB:
+            pairs.append((i, j))
+            onlyB.remove(j)
+        else:
+            onlyA.append(i)
+    rep["matched"] = len(pairs)
+    rep["matched_box_max_abs"] = max([float((A["boxes"][i] - B["boxes"][j]).abs().max()) for i, j in pairs] or [0.0])
+    rep["matched_score_max_abs"] = max([abs(float(A["scores"][i] - B["scores"][j])) for i, j in pairs] or [0.0])
+    rep["only"] = []
+    unexplained = []
+
+    def explain(X, Y, i, who, pair_of):
+        box, cls, s = X["boxes"][i], int(X["classes"][i]), float(X["scores"][i])
+        item = dict(side=who, score=s, cls=cls, box=[round(float(v), 2) for v in box])
+        yb, ys, yc = _cands(Y, 0.0)
+        sel = (yc == cls).nonzero()[:, 0]
+        uu = _iou_matrix(box[None], yb[sel])[0] if sel.numel() else torch.zeros(0, dtype=torch.double)
+        if not sel.numel() or float(uu.max()) < match_iou:
+            item["why"] = "no counterpart candidate in the other run"
+            return item, False
+        c = sel[int(uu.argmax())]
+        sy = float(ys[c])
+        item.update(other_score=sy, score_margin_to_thr=round(s - score_thr, 6), other_margin_to_thr=round(sy - score_thr, 6))
+        if sy <= score_thr:
+            # the noise band this disagreement is held against excludes the candidate itself (and its near-duplicates)
+            far = _iou_matrix(box[None], pair_box)[0] < 0.5 if pair_box.shape[0] else torch.zeros(0, dtype=torch.bool)
+            eps_here = float(pair_ds[far].max()) if int(far.sum()) else 0.0
+            item.update(why="score threshold", score_diff=round(abs(s - sy), 6), eps_score_of_the_others=round(eps_here, 6))
+            return item, abs(s - sy) <= max(eps_here, 1e-6)
+        # above threshold in Y but not kept: suppressed by a kept Y detection of the same class
+        ksel = (Y["classes"] == cls).nonzero()[:, 0]
+        if not ksel.numel():
+            item["why"] = "above threshold in the other run, not kept, no suppressor of that class"
+            return item, False
+        uy = _iou_matrix(yb[c][None], Y["boxes"][ksel])[0]
+        j = int(ksel[int(uy.argmax())])
+        u_y = float(uy.max())
+        jx = pair_of.get(j)
+        item.update(why="nms", iou_in_other=round(u_y, 6), nms_margin_other=round(u_y - nms_thr, 6))
+        if u_y <= nms_thr or jx is None:
+            return item, False
+        u_x = float(_iou_matrix(box[None], X["boxes"][jx][None])[0, 0])
+        other = _iou_matrix(box[None], sub_box)[0] < match_iou if sub_box.shape[0] else torch.zeros(0, dtype=torch.bool)
+        eps_here = float(du[other][:, other].max()) if int(other.sum()) else 0.0      # IoU noise of the pairs not involving it
+        item.update(iou_here=round(u_x, 6), nms_margin_here=round(u_x - nms_thr, 6), iou_diff=round(u_y - u_x, 6),
+                    eps_iou_of_the_others=round(eps_here, 6))
+        return item, (u_x <= nms_thr and (u_y - u_x) <= max(eps_here, 1e-6))
+
+    a_of_b = {j: i for i, j in pairs}
+    b_of_a = {i: j for i, j in pairs}
+    for i in onlyA:
+        item, good = explain(A, B, i, "A", a_of_b)
+        item["explained"] = bool(good)
+        rep["only"].append(item)
+        if not good:
+            unexplained.append(item)
+    for j in onlyB:
+        item, good = explain(B, A, j, "B", b_of_a)
+        item["explained"] = bool(good)
+        rep["only"].append(item)
+        if not good:
+            unexplained.append(item)
+    return rep, unexplained

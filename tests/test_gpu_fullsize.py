@@ -48,26 +48,39 @@ def test_full_frame_vs_oracle(env, logdir):
     img = np.asarray(Image.fromarray(frame).resize((iw, ih), Image.BILINEAR))
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     post = DetectorOracle(env["sd"]).inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), *FRAME)
+    # Bars: each limit is <= 10x what this test observes on MI355X (logged below; round-2 observations in brackets) and every
+    # float limit sits inside north_star's 1e-3 (pixel positions / distances), index results are exact.
     for k in ("p2", "p4", "p6"):
         got, ref = feats[k].cpu(), post["features"][k]
         d = float((got - ref).abs().max() / ref.abs().max())
         _log(logdir, "feat/" + k, dict(rel=d))
-        assert d < 2e-4                                   # f32 through 104 convolutions, different sum order
+        assert d < 3e-5                                   # [2.8e-6] f32 through 104 convolutions, different sum order
     model = tr.predictor.model
     P = int(model.last_results.prop_count[0])
     ref_props = post["proposals"]["boxes"]
     props = model.debug_tensor("proposals").cpu().view(-1, 4)[:P]
-    same_p = int((props - ref_props[:P]).abs().max(dim=1).values.lt(0.05).sum()) if P == ref_props.shape[0] else -1
-    _log(logdir, "rpn", dict(P=P, ref_P=int(ref_props.shape[0]), rows_equal=same_p))
     assert P == ref_props.shape[0]
-    assert same_p >= P - 20                               # near-tied logits at rank ~1000 may swap a few rows
+    row_err = (props - ref_props[:P]).abs().max(dim=1).values
+    same_p = int(row_err.lt(1e-3).sum())
+    # rows that differ are ORDER swaps of near-tied objectness logits around the rank-1000 cut: as a set the proposals agree
+    d2 = torch.cdist(props.double(), ref_props.double(), p=float("inf"))
+    set_err = float(torch.maximum(d2.min(dim=1).values.max(), d2.min(dim=0).values.max()))
+    _log(logdir, "rpn", dict(P=P, ref_P=int(ref_props.shape[0]), rows_equal=same_p, rows_max_abs_when_equal=float(row_err[row_err < 1e-3].max()),
+                             set_max_abs=set_err))
+    assert same_p >= P - 12                               # [994 of 1000 rows in place, 6 swapped]
+    assert float(row_err[row_err < 1e-3].max()) < 5e-4 and set_err < 1.0
     n = len(inst)
-    _log(logdir, "dets", dict(n=n, ref_n=int(post["boxes"].shape[0]), scores=[round(float(s), 5) for s in inst.scores],
-                              ref=[round(float(s), 5) for s in post["scores"]]))
-    assert n == post["boxes"].shape[0]
+    from hip_helpers import explain_detection_sets, hip_box_side, oracle_box_side
+    rep, unexplained = explain_detection_sets(hip_box_side(model), oracle_box_side(post))
+    db = float((inst.pred_boxes.tensor - post["boxes"]).abs().max()) if n == post["boxes"].shape[0] else -1.0
+    ds = float((inst.scores - post["scores"]).abs().max()) if n == post["boxes"].shape[0] else -1.0
+    _log(logdir, "dets", dict(n=n, ref_n=int(post["boxes"].shape[0]), box_max_abs_px=db, score_max_abs=ds, analysis=rep,
+                              scores=[round(float(s), 5) for s in inst.scores], ref=[round(float(s), 5) for s in post["scores"]]))
+    assert n == post["boxes"].shape[0] and not rep["only"]                # same detection set: ids / box indices exact
     assert torch.equal(inst.pred_classes, post["classes"])
-    assert float((inst.pred_boxes.tensor - post["boxes"]).abs().max()) < 0.1        # 4K frame pixels
-    assert float((inst.scores - post["scores"]).abs().max()) < 1e-4
+    assert db < 1e-3                                      # [1.2e-4] 4K frame pixels: north_star's bar
+    assert ds < 2e-6                                      # [1.8e-7]
+    assert rep["eps_score"] < 2e-5 and rep["eps_box_px"] < 1e-3       # every candidate above 0.3, not only the kept ones
     bad = tot = 0
     for k in range(n):
         m = inst.pred_masks[k]
@@ -75,13 +88,13 @@ def test_full_frame_vs_oracle(env, logdir):
         bad += int((m.window().cpu() != post["mask_windows"][k]).sum())
         tot += int(m.mass)
     _log(logdir, "masks", dict(mismatched=bad, total=tot))
-    assert bad <= max(16, tot // 5000)            # >= 0.5 threshold on f32 bilinear values: edge pixels may flip
+    assert bad <= 40                                      # [4 of 130 557] >= 0.5 on f32 bilinear values: edge pixels may flip
     if n:
         rois = otr.features_rois(post["features"]["p2"], post["boxes"], FRAME[1])
         emb = otr.association_head(rois, env["asd"]["fc.weight"], env["asd"]["fc.bias"])
         de = float((torch.from_numpy(inst._record["embeddings"]) - emb).abs().max())
         _log(logdir, "emb", dict(max_abs=de))
-        assert de < 2e-3
+        assert de < 6e-6                                  # [6.0e-7] unit vectors
 
 
 def test_determinism_and_batch_equivalence(env):
@@ -159,11 +172,7 @@ def test_4k_sequence_ids_and_csv_vs_oracle(env, logdir):
         _log(logdir, "seq4k/%d" % t, dict(ids=list(objs.ids) if len(objs) else [], ref_ids=orec["ids"], same_line=line == oline))
         assert (list(objs.ids) if len(objs) else []) == orec["ids"]
         same += int(line == oline)
-        if line != oline:                     # a threshold-edge pixel may move one integer cell by 1
-            a, b = line.split(","), oline.split(",")
-            assert len(a) == len(b)
-            assert all(x == y or abs(float(x) - float(y)) <= 1.0 for x, y in zip(a, b))
-    assert same >= 3
+    assert same == 4                          # [4 of 4] integer cells: every CSV line equal to the oracle's text
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
@@ -171,10 +180,14 @@ def test_full_frame_16bit_vs_oracle(env, logdir, dtype):
     """BASELINE configs 3 / 5 precision at full size: 16-bit matrix cores and 16-bit activation storage (this is where the
     256x128 tile and the deep-K 16-bit shapes are live) against the oracle with the same rounding points
     (operands AND stored tensors rounded to the 16-bit type).  A different f32 accumulation order can flip a 16-bit
-    rounding (2^-9 / 2^-11 relative) of a next-layer input, so features are compared on mean error and the detections
-    after matching by box; parity unpinned like the f32 detector (oracle restates detectron2)."""
+    rounding (2^-9 / 2^-11 relative) of a next-layer input, so features are compared on mean error.  Detections: the two
+    runs must keep the SAME set (then ids / box indices are exact) except for candidates that sit within the measured
+    16-bit noise of a decision threshold -- score 0.5 or NMS IoU 0.5 -- which hip_helpers.explain_detection_sets proves
+    one by one (noise measured on all the other candidates of the same frame); any other difference fails the test.
+    Parity unpinned like the f32 detector (oracle restates detectron2)."""
     from PIL import Image
     from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from hip_helpers import explain_detection_sets, hip_box_side, oracle_box_side
     from oracle.detector import DetectorOracle, resize_shape
     cfg = env["cfg"].clone()
     cfg.APSE.MAX_BATCH = 1
@@ -184,11 +197,14 @@ def test_full_frame_16bit_vs_oracle(env, logdir, dtype):
     frame = env["seq"].frame(0)
     pred, feats = tr.predictor(frame)
     inst = pred["instances"]
+    model = tr.predictor.model
+    hip_side = hip_box_side(model)
     ih, iw = resize_shape(*FRAME)
     img = np.asarray(Image.fromarray(frame).resize((iw, ih), Image.BILINEAR))
+    x = torch.as_tensor(img.astype("float32").transpose(2, 0, 1))
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     oracle = DetectorOracle(env["sd"], dict(bf16=("f16" if dtype == "f16" else True), storage16=True))
-    post = oracle.inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), *FRAME)
+    post = oracle.inference(x, *FRAME)
     lim_max, lim_mean = (6e-2, 1.5e-2) if dtype == "bf16" else (1e-2, 2.5e-3)
     for k in ("p2", "p4", "p6"):
         got, ref = feats[k].cpu(), post["features"][k]
@@ -196,16 +212,20 @@ def test_full_frame_16bit_vs_oracle(env, logdir, dtype):
         mean = float((got - ref).abs().mean() / ref.abs().mean())
         _log(logdir, dtype + "/feat/" + k, dict(rel_max=d, rel_mean=mean))
         assert d < lim_max and mean < lim_mean
-    n, rn = len(inst), int(post["boxes"].shape[0])
-    matched = 0
-    for k in range(n):
-        dd = (post["boxes"] - inst.pred_boxes.tensor[k]).abs().max(dim=1).values if rn else torch.tensor([])
-        j = int(dd.argmin()) if rn else -1
-        if rn and float(dd[j]) < 8.0 and int(post["classes"][j]) == int(inst.pred_classes[k]):      # 4K pixels
-            matched += 1
-    _log(logdir, dtype + "/dets", dict(n=n, ref_n=rn, matched=matched, scores=[round(float(s), 4) for s in inst.scores],
+    rep, unexplained = explain_detection_sets(hip_side, oracle_box_side(post))
+    _log(logdir, dtype + "/dets", dict(analysis=rep, unexplained=unexplained, scores=[round(float(s), 4) for s in inst.scores],
                                        ref=[round(float(s), 4) for s in post["scores"]]))
-    assert abs(n - rn) <= 2 and matched >= min(n, rn) - 2
+    assert not unexplained, unexplained
+    assert rep["matched"] == rep["nA"] - sum(1 for o in rep["only"] if o["side"] == "A")
+    assert rep["matched"] >= 1
+    # the f32 run of the same frame is the second witness: its detections, too, differ from the 16-bit ones only at thresholds
+    post32 = DetectorOracle(env["sd"]).inference(x, *FRAME)
+    rep32, un32 = explain_detection_sets(hip_side, oracle_box_side(post32))
+    _log(logdir, dtype + "/dets_vs_f32_oracle", dict(analysis=rep32, unexplained=un32))
+    assert not un32, un32
+    # 16-bit noise of what both runs keep (frame pixels = resized pixels x 2.88): logged, bounded loosely
+    assert rep["matched_score_max_abs"] < (2e-2 if dtype == "bf16" else 5e-3)
+    assert rep["matched_box_max_abs"] < (2.0 if dtype == "bf16" else 0.5)
 
 
 def test_4k_results_independent_of_history(env, logdir):
@@ -259,3 +279,106 @@ def test_4k_shards_and_pipeline_equal_sequential(env, logdir):
     assert same_recs == n
     assert lines == ref_lines and lines_native == ref_lines
     assert plines == ref_lines
+
+
+def _record_bytes(inst):
+    r = inst._record
+    return b"".join(np.ascontiguousarray(r[k]).tobytes() for k in ("boxes", "scores", "classes", "centroids", "mass", "rects",
+                                                                   "closest", "embeddings"))
+
+
+def _batch_equals_singles(cfg, env, frames, logdir, tag, camera=None):
+    """One context (MAX_BATCH = len(frames)): the batch forward and the per-frame forwards must give the same BYTES per
+    image (boxes, scores, classes, centroids, masses, rects, closest-point table, embeddings) -- a frame's results do not
+    depend on its batch neighbours -- and therefore the same track ids and CSV text."""
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    tr = RcnnTracker(cfg, FRAME, env["asd"], detector_state=env["sd"])
+    if camera is not None:
+        tr.predictor.set_camera(camera)
+    batch = [o["instances"] for o in tr.predictor.predict_batch(frames, want_masks=False)[0]]
+    singles = [tr.predictor.predict_batch([f], want_masks=False)[0][0]["instances"] for f in frames]
+    same = [(_record_bytes(a) == _record_bytes(b)) for a, b in zip(batch, singles)]
+    lines = []
+    for dets in (batch, singles):
+        tr.reset_tracker()
+        out = []
+        for t, d in enumerate(dets):
+            tr.frame_count += 1
+            objs = tr._finish_frame(d, None, host_replay=True)
+            out.append((list(objs.ids) if len(objs) else [], tr.log_line(objs, 1, t)[0]))
+        lines.append(out)
+    _log(logdir, tag, dict(n=[len(b) for b in batch], bytes_equal=same, ids=[l[0] for l in lines[0]]))
+    assert all(len(b) > 0 for b in batch)
+    assert all(same)
+    assert lines[0] == lines[1]
+
+
+def test_config3_bf16_batch4_with_preproc_equals_batch1(env, logdir, golden_dir):
+    """BASELINE configs[2] at full size: dynamic 3840x2160 frames, batch 4, bf16 matrix cores + storage, undistort + gamma HIP
+    pre-processing (data/cam_params.json) in front of the resize."""
+    with open(os.path.join(golden_dir, "cam_params.json")) as f:
+        cam = json.load(f)
+    cfg = env["cfg"].clone()
+    cfg.APSE.MAX_BATCH = 4
+    cfg.APSE.DTYPE = "bf16"
+    cfg.APSE.STORAGE16 = True
+    frames = [env["seq"].frame(t) for t in (0, 12, 27, 45)]           # vehicle 1 is out of the picture in the third
+    _batch_equals_singles(cfg, env, frames, logdir, "config3_b4_bf16", camera=cam)
+
+
+def test_config5_f16_batch8_equals_batch1(env, logdir):
+    """BASELINE configs[4] on one GPU: synthetic 3840x2160 stream, batch 8 per GPU, fp16."""
+    cfg = env["cfg"].clone()
+    cfg.APSE.MAX_BATCH = 8
+    cfg.APSE.DTYPE = "f16"
+    cfg.APSE.STORAGE16 = True
+    frames = [env["seq"].frame(6 * t) for t in range(8)]
+    _batch_equals_singles(cfg, env, frames, logdir, "config5_b8_f16")
+
+
+def test_config2_static64_csv_vs_oracle(env, logdir, tmp_path, golden_dir):
+    """BASELINE configs[1] as SURVEY 8d restates it: the "static" 64-frame 3840x2160 sequence, batch 1 f32, through
+    RcnnTracker.next_frame; CSV text against the oracle's CSV, then the consumer layout against the shipped header.
+    The static sequence has zero motion, so its frames are identical arrays: the oracle DETECTOR runs once, the
+    oracle TRACKER (ids, association, log line) runs all 64 steps."""
+    from PIL import Image
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from apse_uav_amd.synthetic import SyntheticSequence
+    from apse_uav_amd.utils import csv_log
+    from oracle import tracker as otr
+    from oracle.detector import DetectorOracle, resize_shape
+    seq = SyntheticSequence("static", *FRAME)
+    f0 = seq.frame(0)
+    assert np.array_equal(f0, seq.frame(63))
+    cfg = env["cfg"].clone()
+    cfg.APSE.MAX_BATCH = 1
+    tr = RcnnTracker(cfg, FRAME, env["asd"], detector_state=env["sd"])
+    lines, max_id = [], 0
+    for t in range(64):
+        objs = tr.next_frame(seq.frame(t), upcoming=None)
+        line, hi = tr.log_line(objs, 1, t)
+        lines.append(line)
+        max_id = max(max_id, hi)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ih, iw = resize_shape(*FRAME)
+    img = np.asarray(Image.fromarray(f0).resize((iw, ih), Image.BILINEAR))
+    post = DetectorOracle(env["sd"]).inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), *FRAME)
+    rois = otr.features_rois(post["features"]["p2"], post["boxes"], FRAME[1])
+    emb = otr.association_head(rois, env["asd"]["fc.weight"], env["asd"]["fc.bias"])
+    otk = otr.TrackerOracle()
+    olines = []
+    for t in range(64):
+        orec = otk.next_frame(dict(boxes=post["boxes"], scores=post["scores"], classes=post["classes"],
+                                   masks=list(zip(post["mask_windows"], post["mask_rects"])), emb=emb))
+        olines.append(otr.log_oneline(orec, 1, t)[0])
+    same = sum(a == b for a, b in zip(lines, olines))
+    _log(logdir, "config2_static64", dict(same_lines=same, n=64, max_id=max_id, sample=lines[63][:96]))
+    assert same == 64
+    path = tmp_path / "static_dcnn_data.csv"
+    csv_log.write_consumer_csv(str(path), lines, host_id=1, vehicle_ids=[2, 3, 4])
+    with open(path) as f, open(os.path.join(golden_dir, "static_dcnn_data_head.csv")) as g:
+        got, ref = f.read().split("\n"), g.read().split("\n")
+    assert got[0].split(",")[0].startswith("Host id:") and len(got[0].split(",")) == len(ref[0].split(","))
+    assert [c.split(" ")[-1] for c in got[1].split(",")] == [c.split(" ")[-1] for c in ref[1].split(",")]      # frame, cent_x, cent_y, clos_x, ...
+    data = csv_log.read_centroid_data(str(path))
+    assert len(data) == 64 and all(len(r) == 17 for r in data) and [r[0] for r in data] == list(range(64))
