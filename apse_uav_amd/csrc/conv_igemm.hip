@@ -669,6 +669,8 @@ static int launch_cfg_k2(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hip
 int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (p.M <= 0 || p.Cout <= 0 || p.steps_total <= 0) return APSE_E_INVALID;
     if (p.res_mode != 0 && (p.Cout & 3) != 0) return APSE_E_INVALID;      // residual rows are read as float4
+    if (cfg == APSE_CFG_STREAM && (p.no_stream || !apse_conv1x1_stream_ok(p))) return APSE_E_INVALID;
+    if (!p.no_stream && apse_conv1x1_stream_ok(p)) return apse_launch_conv1x1_stream(p, s, ev0, ev1);
     if (p.prec == 1 || p.prec == 2) {
         // operands already stored 16-bit, filter rows a whole number of 64-element steps: the scheduled kernel
         const bool fast16 = p.w16 && p.x_st == p.prec && (p.KWCp & 63) == 0 && p.cin_log2 >= 3 &&

@@ -111,7 +111,7 @@ struct apse_ctx {
     // per-kernel profiling with HIP events on the caller's stream (bench.py roofline)
     bool prof_on = false; std::vector<hipEvent_t> ev_pool; int ev_used = 0;
     struct Pending { int cfg; double flops_per_item; int count_kind; int b_mult; int batch; int e0, e1; };
-    std::vector<Pending> pending; double prof[8][3] = {{0}};
+    std::vector<Pending> pending; double prof[APSE_NCFG][3] = {{0}};
     // stateless-op scratch
     uint64_t* op_bits = nullptr; unsigned long long* op_sums = nullptr; size_t op_bits_words = 0;
 };
@@ -382,6 +382,7 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
             }
             if (c->prof_on && c->ev_used + 2 <= (int)c->ev_pool.size()) { e0 = c->ev_used; c->ev_used += 2; }
             rc = apse_launch_conv(p, cfg, s, e0 >= 0 ? c->ev_pool[e0] : nullptr, e0 >= 0 ? c->ev_pool[e0 + 1] : nullptr);
+            if (apse_conv1x1_stream_ok(p)) cfg = APSE_CFG_STREAM;             // profile label of the kernel that actually ran
             if (e0 >= 0) c->pending.push_back({cfg, st.c.flops_per_item, st.c.count_kind, st.c.b_mult, batch, e0, e0 + 1});
         } else if (st.kind == S_MAXPOOL) {
             rc = apse_k_maxpool3x3s2(st.x, st.y, batch, st.H, st.W, st.C, st.st, s);
@@ -965,9 +966,9 @@ int apse_profile(apse_ctx* c, int enable) {
     return APSE_OK;
 }
 
-int apse_profile_read(apse_ctx* c, double* out24, int reset) {
-    if (!c || !out24) return APSE_E_INVALID;
-    memcpy(out24, c->prof, sizeof(c->prof));
+int apse_profile_read(apse_ctx* c, double* out30, int reset) {
+    if (!c || !out30) return APSE_E_INVALID;
+    memcpy(out30, c->prof, sizeof(c->prof));
     if (reset) memset(c->prof, 0, sizeof(c->prof));
     return APSE_OK;
 }
@@ -1115,7 +1116,7 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
     if (p.x_st && cin_p < 8) return APSE_E_INVALID;
     int sk = 1;
     int cfg = apse_conv_pick_cfg(p.M, p.Cout, p.steps_total, &sk);
-    if (d->cfg >= 0) { cfg = d->cfg; sk = 1; }
+    if (d->cfg >= 0) { cfg = d->cfg; sk = 1; p.no_stream = (d->cfg != APSE_CFG_STREAM); }
     if (d->splitk > 0) sk = d->splitk;
     if (sk > p.steps_total) sk = p.steps_total;
     p.splitk = sk;

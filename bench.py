@@ -26,11 +26,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CFG_NAMES = ["conv_igemm<128x128>", "conv_igemm<64x64>", "conv_igemm<128x32>", "conv_igemm<128x64>",
-             "conv_igemm<64x64,k32>", "conv_igemm<128x32,k32>", "conv_igemm<64x64,8 waves,k64>", "conv_igemm<64x64,8 waves,k128>"]
+             "conv_igemm<64x64,k32>", "conv_igemm<128x32,k32>", "conv_igemm<64x64,8 waves,k64>", "conv_igemm<64x64,8 waves,k128>",
+             "conv_igemm<256x128>", "conv1x1_stream"]
 # template arguments <WM, WN, TM, TN, KS, XT, WK, PR> of conv_igemm_f32 behind each tile shape (f32 path, f32 activations):
 # the kernel names rocprofv3 reports, used to look the dominant kernel up in the committed PMC summary
 CFG_TEMPLATE = ["<2, 2, 2, 2, 1, 0, 1, 0>", "<2, 2, 1, 1, 2, 0, 1, 0>", "<4, 1, 1, 1, 2, 0, 1, 0>", "<4, 1, 1, 2, 1, 0, 1, 0>",
-                "<2, 2, 1, 1, 1, 0, 1, 0>", "<4, 1, 1, 1, 1, 0, 1, 0>", "<2, 2, 1, 1, 2, 0, 2, 0>", "<2, 2, 1, 1, 4, 0, 2, 0>"]
+                "<2, 2, 1, 1, 1, 0, 1, 0>", "<4, 1, 1, 1, 1, 0, 1, 0>", "<2, 2, 1, 1, 2, 0, 2, 0>", "<2, 2, 1, 1, 4, 0, 2, 0>", None, None]
+NCFG = len(CFG_NAMES)
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_latest.json")
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 dense
@@ -249,12 +251,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     import ctypes as C
-    prof = np.zeros((8, 3))
+    prof = np.zeros((NCFG, 3))
     for m in models:
-        pr = (C.c_double * 24)()
+        pr = (C.c_double * (3 * NCFG))()
         lib.apse_profile_read(m._ctx, C.byref(pr), 1)
         lib.apse_profile(m._ctx, 0)
-        prof += np.array(list(pr)).reshape(8, 3)
+        prof += np.array(list(pr)).reshape(NCFG, 3)
 
     if rank == 0:
         frames_total = args.steps * B * world
@@ -273,7 +275,7 @@ def main():
             try:
                 with open(PMC_TRAFFIC_FILE) as fh:
                     pmj = json.load(fh)
-                pm = pmj.get("conv_igemm_f32" + CFG_TEMPLATE[dom])
+                pm = pmj.get("conv_igemm_f32" + CFG_TEMPLATE[dom]) if CFG_TEMPLATE[dom] else None
                 if pmj.get("__build__") != build:
                     traffic_src = ("null: profiles/pmc_traffic_latest.json was recorded for build '%s', the loaded library is "
                                    "'%s' (re-run tools/gpu_profile_round.sh)" % (pmj.get("__build__"), build))
@@ -298,7 +300,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(ms / max(nl, 1), 5), "launches": int(nl),
                          "all_kernels": {CFG_NAMES[k]: {"ms": round(float(prof[k, 0]), 3),
                                                         "tflops": round(float(prof[k, 1] / max(prof[k, 0], 1e-9) / 1e9), 3),
-                                                        "launches": int(prof[k, 2])} for k in range(8) if prof[k, 2] > 0},
+                                                        "launches": int(prof[k, 2])} for k in range(NCFG) if prof[k, 2] > 0},
                          "conv_ms_per_frame": round(total_conv_ms / max(n_instr * B, 1), 3), "instrumented_steps": n_instr,
                          "whole_path_tflops": round(flops_frame * fps / world / 1e12, 3)},
         }

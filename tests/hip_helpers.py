@@ -136,66 +136,126 @@ def oracle_box_side(post):
     return dict(all_boxes=d["all_boxes"], probs=d["probs"], boxes=d["boxes"], scores=d["scores"], classes=d["classes"])
 
 
-def _cands(side, min_score):
+def _flat_box_side(side):
+    """(proposal, class) candidates of the box branch as flat arrays; live = score above the test threshold is applied later."""
     K = side["probs"].shape[1] - 1
-    s = side["probs"][:, :K].reshape(-1)
-    cls = torch.arange(K).repeat(side["probs"].shape[0])
-    keep = s > min_score
-    return side["all_boxes"].reshape(-1, 4)[keep], s[keep], cls[keep]
+    n = side["probs"].shape[0]
+    return dict(cand_boxes=side["all_boxes"].reshape(-1, 4), cand_scores=side["probs"][:, :K].reshape(-1),
+                cand_cat=torch.arange(K).repeat(n), cand_src=torch.arange(n).repeat_interleave(K),
+                boxes=side["boxes"], scores=side["scores"], cats=side["classes"])
+
+
+def hip_rpn_side(model, b=0):
+    """RPN selection view of image ``b``: the pre-NMS candidates (top-k per level, decoded + clipped) and the proposals kept."""
+    g = model._cfg_c
+    PRE, POST = g.rpn_pre_topk, g.rpn_post_topk
+    res = model.last_results
+    P = int(res.prop_count[b])
+    dec = model.debug_tensor("rpn_decoded").cpu().view(-1, 5 * PRE, 4)[b]
+    sc = model.debug_tensor("rpn_decoded_scores").cpu().view(-1, 5 * PRE)[b]
+    ok = model.debug_tensor("rpn_decoded_valid", torch.int32).cpu().view(-1, 5 * PRE)[b] != 0
+    lvl = torch.arange(5 * PRE) // PRE
+    props = model.debug_tensor("proposals").cpu().view(-1, POST, 4)[b, :P]
+    psc = model.debug_tensor("proposal_scores").cpu().view(-1, POST)[b, :P]
+    pent = model.debug_tensor("proposal_entry", torch.int32).cpu().view(-1, POST)[b, :P].long()
+    return dict(cand_boxes=dec[ok], cand_scores=sc[ok], cand_cat=lvl[ok], boxes=props, scores=psc, cats=pent // PRE)
+
+
+def oracle_rpn_side(post):
+    pr = post["proposals"]
+    lv = torch.cat([torch.full((t.numel(),), i, dtype=torch.int64) for i, t in enumerate(pr["topk_scores"])])
+    sc = torch.cat(pr["topk_scores"])
+    ok = pr["valid"]
+    return dict(cand_boxes=pr["decoded"][ok], cand_scores=sc[ok], cand_cat=lv[ok], boxes=pr["boxes"], scores=pr["logits"],
+                cats=pr["level"])
 
 
 def explain_detection_sets(A, B, score_thr=0.5, nms_thr=0.5, match_iou=0.9):
-    """Compares the detection sets of two runs of the box branch (HIP vs oracle, f32 vs 16-bit, ...).
+    """Box-branch form of ``explain_sets`` (sides from hip_box_side / oracle_box_side)."""
+    return explain_sets(_flat_box_side(A), _flat_box_side(B), score_thr, nms_thr, match_iou=match_iou, noise_floor=0.3)
 
-    Returns (report, unexplained).  Detections are paired by class and IoU >= match_iou.  The numeric noise between the
-    two runs is MEASURED on the candidates both runs score above 0.3: eps_score = max |score_A - score_B| and eps_iou =
-    max |IoU_A(i, j) - IoU_B(i, j)| over candidate pairs whose IoU lies in (0.3, 0.8).  A detection only one run keeps
-    is *explained* when the other run holds the same candidate (same class, IoU >= match_iou) and either
-      (score) that candidate's score is on the other side of score_thr and within eps_score of the kept one (eps_score
-              taken over the OTHER candidates: the disputed one does not vouch for itself), or
-      (nms)   it was suppressed there by a kept detection with IoU u > nms_thr while the same pair has IoU <= nms_thr in
-              the run that keeps it, and the two IoUs differ by at most eps_iou.
-    Anything else is returned in ``unexplained`` (a bug to find, not noise)."""
+
+def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise_floor=None):
+    """Compares what two runs of one selection stage keep (HIP vs oracle, f32 vs 16-bit, ...).
+
+    A side = dict(cand_boxes [n,4], cand_scores [n], cand_cat [n]  -- every candidate the stage ranks (category = class
+    for the box branch, pyramid level for the RPN); boxes / scores / cats -- what it keeps after the score threshold
+    (``score_thr``, None for the RPN), per-category NMS at ``nms_thr`` and the top-``rank_limit`` cut).
+    Returns (report, unexplained).  Kept items are paired by category and IoU >= match_iou.  The numeric noise between
+    the runs is MEASURED on the candidates both hold (scores above ``noise_floor`` when given): eps_score = max
+    |score_A - score_B| and eps_iou = max |IoU_A(i, j) - IoU_B(i, j)| over candidate pairs with IoU in (0.3, 0.8) --
+    in both cases taken over the OTHER candidates: a disputed one does not vouch for itself.  An item only one run
+    keeps is *explained* when the other run holds the same candidate and either
+      (score) its score there is on the other side of score_thr, within eps_score of the kept one, or
+      (nms)   it was suppressed there by a kept item with IoU u > nms_thr while the same pair has IoU <= nms_thr in the
+              run that keeps it, and the two IoUs differ by at most eps_iou, or
+      (rank)  it falls past the top-``rank_limit`` cut there with a score within eps_score of that run's last kept one.
+    "Within eps" means within BAND x the largest deviation seen on the other candidates (BAND = 1.5: the disputed item is
+    one more draw from the same noise, and the maximum of ~10^2 draws is exceeded by a fresh one about once in 10^2).
+    Everything else -- including "the other run has no such candidate" -- is returned in ``unexplained``."""
+    BAND = 1.5
     rep = dict(nA=int(A["boxes"].shape[0]), nB=int(B["boxes"].shape[0]))
-    ca = _cands(A, 0.3)
-    cb = _cands(B, 0.2)
-    iou = _iou_matrix(ca[0], cb[0])
-    same = ca[2][:, None] == cb[2][None, :]
-    iou_m = torch.where(same, iou, torch.zeros_like(iou))
-    best, arg = iou_m.max(dim=1) if cb[0].shape[0] else (torch.zeros(ca[0].shape[0], dtype=torch.double), None)
-    ok = best >= match_iou
-    rep["cand_pairs"] = int(ok.sum())
-    eps_s = eps_box = eps_iou = 0.0
+    fa = A["cand_scores"] > noise_floor if noise_floor is not None else torch.ones_like(A["cand_scores"], dtype=torch.bool)
+    ca = (A["cand_boxes"][fa], A["cand_scores"][fa], A["cand_cat"][fa])
+    if ca[0].shape[0] > 3000:                       # noise sample: the best-scored candidates are enough
+        top = torch.argsort(ca[1], descending=True)[:3000]
+        ca = (ca[0][top], ca[1][top], ca[2][top])
+    cb = (B["cand_boxes"], B["cand_scores"], B["cand_cat"])
     pair_box = torch.zeros((0, 4))
     pair_ds = torch.zeros((0,))
     sub_box = torch.zeros((0, 4))
     du = torch.zeros((0, 0), dtype=torch.double)
-    if int(ok.sum()):
-        ia = ok.nonzero()[:, 0]
-        ib = arg[ia]
-        pair_box, pair_ds = ca[0][ia], (ca[1][ia] - cb[1][ib]).abs()
-        eps_s = float(pair_ds.max())
-        eps_box = float((ca[0][ia] - cb[0][ib]).abs().max())
-        ia, ib = ia[:400], ib[:400]
-        sub_box = ca[0][ia]
-        ua, ub = _iou_matrix(sub_box, sub_box), _iou_matrix(cb[0][ib], cb[0][ib])
-        band = (ua > 0.3) & (ua < 0.8)
-        du = (ua - ub).abs() * band
-        if int(band.sum()):
-            eps_iou = float(du.max())
-    rep.update(eps_score=eps_s, eps_box_px=eps_box, eps_iou=eps_iou)
-    # pair the kept detections
+    eps_s = eps_box = eps_iou = 0.0
+    n_pairs = 0
+    if ca[0].shape[0] and cb[0].shape[0]:
+        best = torch.zeros(ca[0].shape[0], dtype=torch.double)
+        arg = torch.zeros(ca[0].shape[0], dtype=torch.long)
+        for cat in ca[2].unique().tolist():          # per category: keeps the IoU matrices small
+            ia_ = (ca[2] == cat).nonzero()[:, 0]
+            ib_ = (cb[2] == cat).nonzero()[:, 0]
+            if not ib_.numel():
+                continue
+            for lo in range(0, ia_.numel(), 1024):
+                blk = ia_[lo:lo + 1024]
+                m, a = _iou_matrix(ca[0][blk], cb[0][ib_]).max(dim=1)
+                best[blk], arg[blk] = m, ib_[a]
+        ok = best >= match_iou
+        n_pairs = int(ok.sum())
+        if n_pairs:
+            ia = ok.nonzero()[:, 0]
+            ib = arg[ia]
+            pair_box, pair_ds = ca[0][ia], (ca[1][ia] - cb[1][ib]).abs()
+            eps_s = float(pair_ds.max())
+            eps_box = float((ca[0][ia] - cb[0][ib]).abs().max())
+            ia, ib = ia[:400], ib[:400]
+            sub_box = ca[0][ia]
+            ua, ub = _iou_matrix(sub_box, sub_box), _iou_matrix(cb[0][ib], cb[0][ib])
+            band = (ua > 0.3) & (ua < 0.8)
+            du = (ua - ub).abs() * band
+            if int(band.sum()):
+                eps_iou = float(du.max())
+    rep.update(cand_pairs=n_pairs, eps_score=eps_s, eps_box_px=eps_box, eps_iou=eps_iou)
+    # pair the kept items
     pairs, onlyA, onlyB = [], [], list(range(rep["nB"]))
     if rep["nA"] and rep["nB"]:
-        u = _iou_matrix(A["boxes"], B["boxes"])
-        u = torch.where(A["classes"][:, None] == B["classes"][None, :], u, torch.zeros_like(u))
-    for i in range(rep["nA"]):
-        j = int(u[i].argmax()) if rep["nB"] else -1
-        if j >= 0 and float(u[i, j]) >= match_iou and j in onlyB:
-            pairs.append((i, j))
-            onlyB.remove(j)
-        else:
-            onlyA.append(i)
+        for i in range(rep["nA"]):
+            sel = (B["cats"] == A["cats"][i]).nonzero()[:, 0]
+            j = -1
+            if sel.numel():
+                u = _iou_matrix(A["boxes"][i][None], B["boxes"][sel])[0]
+                for k in torch.argsort(u, descending=True).tolist():
+                    if float(u[k]) < match_iou:
+                        break
+                    if int(sel[k]) in onlyB:
+                        j = int(sel[k])
+                        break
+            if j >= 0:
+                pairs.append((i, j))
+                onlyB.remove(j)
+            else:
+                onlyA.append(i)
+    else:
+        onlyA = list(range(rep["nA"]))
     rep["matched"] = len(pairs)
     rep["matched_box_max_abs"] = max([float((A["boxes"][i] - B["boxes"][j]).abs().max()) for i, j in pairs] or [0.0])
     rep["matched_score_max_abs"] = max([abs(float(A["scores"][i] - B["scores"][j])) for i, j in pairs] or [0.0])
@@ -203,41 +263,49 @@ def explain_detection_sets(A, B, score_thr=0.5, nms_thr=0.5, match_iou=0.9):
     unexplained = []
 
     def explain(X, Y, i, who, pair_of):
-        box, cls, s = X["boxes"][i], int(X["classes"][i]), float(X["scores"][i])
-        item = dict(side=who, score=s, cls=cls, box=[round(float(v), 2) for v in box])
-        yb, ys, yc = _cands(Y, 0.0)
-        sel = (yc == cls).nonzero()[:, 0]
+        box, cat, s = X["boxes"][i], int(X["cats"][i]), float(X["scores"][i])
+        item = dict(side=who, index=i, score=s, cat=cat, box=[round(float(v), 2) for v in box])
+        yb, ys, yc = Y["cand_boxes"], Y["cand_scores"], Y["cand_cat"]
+        sel = (yc == cat).nonzero()[:, 0]
         uu = _iou_matrix(box[None], yb[sel])[0] if sel.numel() else torch.zeros(0, dtype=torch.double)
         if not sel.numel() or float(uu.max()) < match_iou:
             item["why"] = "no counterpart candidate in the other run"
+            item["best_iou_in_other"] = round(float(uu.max()), 4) if sel.numel() else 0.0
             return item, False
         c = sel[int(uu.argmax())]
         sy = float(ys[c])
-        item.update(other_score=sy, score_margin_to_thr=round(s - score_thr, 6), other_margin_to_thr=round(sy - score_thr, 6))
-        if sy <= score_thr:
-            # the noise band this disagreement is held against excludes the candidate itself (and its near-duplicates)
-            far = _iou_matrix(box[None], pair_box)[0] < 0.5 if pair_box.shape[0] else torch.zeros(0, dtype=torch.bool)
-            eps_here = float(pair_ds[far].max()) if int(far.sum()) else 0.0
-            item.update(why="score threshold", score_diff=round(abs(s - sy), 6), eps_score_of_the_others=round(eps_here, 6))
-            return item, abs(s - sy) <= max(eps_here, 1e-6)
-        # above threshold in Y but not kept: suppressed by a kept Y detection of the same class
-        ksel = (Y["classes"] == cls).nonzero()[:, 0]
-        if not ksel.numel():
-            item["why"] = "above threshold in the other run, not kept, no suppressor of that class"
-            return item, False
-        uy = _iou_matrix(yb[c][None], Y["boxes"][ksel])[0]
-        j = int(ksel[int(uy.argmax())])
-        u_y = float(uy.max())
-        jx = pair_of.get(j)
-        item.update(why="nms", iou_in_other=round(u_y, 6), nms_margin_other=round(u_y - nms_thr, 6))
-        if u_y <= nms_thr or jx is None:
-            return item, False
-        u_x = float(_iou_matrix(box[None], X["boxes"][jx][None])[0, 0])
-        other = _iou_matrix(box[None], sub_box)[0] < match_iou if sub_box.shape[0] else torch.zeros(0, dtype=torch.bool)
-        eps_here = float(du[other][:, other].max()) if int(other.sum()) else 0.0      # IoU noise of the pairs not involving it
-        item.update(iou_here=round(u_x, 6), nms_margin_here=round(u_x - nms_thr, 6), iou_diff=round(u_y - u_x, 6),
-                    eps_iou_of_the_others=round(eps_here, 6))
-        return item, (u_x <= nms_thr and (u_y - u_x) <= max(eps_here, 1e-6))
+        far = _iou_matrix(box[None], pair_box)[0] < 0.5 if pair_box.shape[0] else torch.zeros(0, dtype=torch.bool)
+        eps_here = float(pair_ds[far].max()) if int(far.sum()) else 0.0       # score noise of the other candidates
+        item.update(other_score=sy, score_diff=round(abs(s - sy), 6), eps_score_of_the_others=round(eps_here, 6))
+        if score_thr is not None:
+            item.update(score_margin_to_thr=round(s - score_thr, 6), other_margin_to_thr=round(sy - score_thr, 6))
+            if sy <= score_thr:
+                item["why"] = "score threshold"
+                return item, abs(s - sy) <= max(BAND * eps_here, 1e-6)
+        # a live candidate in Y that Y does not keep: suppressed by a kept item of its category, or past the rank cut
+        ksel = (Y["cats"] == cat).nonzero()[:, 0]
+        u_y, j = 0.0, -1
+        if ksel.numel():
+            uy = _iou_matrix(yb[c][None], Y["boxes"][ksel])[0]
+            j = int(ksel[int(uy.argmax())])
+            u_y = float(uy.max())
+        if u_y > nms_thr:
+            jx = pair_of.get(j)
+            item.update(why="nms", iou_in_other=round(u_y, 6), nms_margin_other=round(u_y - nms_thr, 6))
+            if jx is None:
+                return item, False
+            u_x = float(_iou_matrix(box[None], X["boxes"][jx][None])[0, 0])
+            other = _iou_matrix(box[None], sub_box)[0] < match_iou if sub_box.shape[0] else torch.zeros(0, dtype=torch.bool)
+            eps_u = float(du[other][:, other].max()) if int(other.sum()) else 0.0      # IoU noise of the pairs not involving it
+            item.update(iou_here=round(u_x, 6), nms_margin_here=round(u_x - nms_thr, 6), iou_diff=round(u_y - u_x, 6),
+                        eps_iou_of_the_others=round(eps_u, 6))
+            return item, (u_x <= nms_thr and (u_y - u_x) <= max(BAND * eps_u, 1e-6))
+        if rank_limit is not None and Y["boxes"].shape[0] >= rank_limit:
+            last = float(Y["scores"].min())
+            item.update(why="rank cut", other_last_kept_score=last, margin_to_last=round(sy - last, 6))
+            return item, (sy <= last + 1e-12 or abs(sy - last) <= max(BAND * eps_here, 1e-6)) and abs(s - sy) <= max(BAND * eps_here, 1e-6)
+        item["why"] = "live in the other run, not kept, no suppressor found"
+        return item, False
 
     a_of_b = {j: i for i, j in pairs}
     b_of_a = {i: j for i, j in pairs}
@@ -254,3 +322,32 @@ def explain_detection_sets(A, B, score_thr=0.5, nms_thr=0.5, match_iou=0.9):
         if not good:
             unexplained.append(item)
     return rep, unexplained
+
+
+def explain_frame(hip_model, post, logf=None, b=0):
+    """Both selection stages of one frame, HIP (side A) vs an oracle run (side B).  A box-branch item whose only problem
+    is "no counterpart candidate" is traced to its PROPOSAL: if the other run lacks that proposal and the RPN-stage
+    analysis explains the proposal's absence (NMS at 0.7 / rank cut inside the measured noise), the item is explained too."""
+    hb, ob = hip_box_side(hip_model, b), oracle_box_side(post)
+    rep_box, un_box = explain_detection_sets(hb, ob)
+    hr, orr = hip_rpn_side(hip_model, b), oracle_rpn_side(post)
+    post_topk = int(hip_model._cfg_c.rpn_post_topk)
+    rep_rpn, un_rpn = explain_sets(hr, orr, None, float(hip_model._cfg_c.rpn_nms), rank_limit=post_topk)
+    res = hip_model.last_results
+    lo, hi = res.image_slice(b)
+    roi = {"A": torch.from_numpy(res.roi[lo:hi].astype(np.int64)), "B": post["box_det"]["roi_index"]}
+    props = {"A": hr["boxes"], "B": orr["boxes"]}
+    explained_rpn = {(o["side"], o["index"]) for o in rep_rpn["only"] if o["explained"]}
+    still = []
+    for item in un_box:
+        if item["why"].startswith("no counterpart"):
+            side = item["side"]
+            r = int(roi[side][item["index"]])
+            item["proposal_index"] = r
+            item["proposal_box"] = [round(float(v), 2) for v in props[side][r]]
+            if (side, r) in explained_rpn:
+                item["why"] = "its proposal is absent from the other run; the RPN-stage analysis explains that absence"
+                item["explained"] = True
+                continue
+        still.append(item)
+    return dict(box=rep_box, rpn=rep_rpn), still + un_rpn

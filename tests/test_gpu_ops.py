@@ -167,6 +167,79 @@ def test_conv2d_16bit_storage(case, prec, logdir):
         assert err_stats(out32, ref32)["rel_to_max"] < 2e-5
 
 
+STREAM_CASES = [
+    # name, B, Cin (= K), H, W, Cout, stride, relu, res_mode      -- the memory-streaming 1x1 kernel (csrc/conv1x1_stream.hip, cfg 9)
+    ("s_k64_n256_res", 1, 64, 24, 40, 256, 1, True, 1),          # res2 conv3: residual + ReLU
+    ("s_k64_n256_ragged", 2, 64, 13, 19, 256, 1, False, 0),      # M = 494: ragged last block, rows past M
+    ("s_k128_n512_res", 1, 128, 18, 26, 512, 1, True, 1),        # res3 conv3
+    ("s_k256_n1024_res", 1, 256, 12, 21, 1024, 1, True, 1),      # res4 conv3 (N chunks split over blockIdx.y)
+    ("s_k256_n256_up", 1, 256, 16, 24, 256, 1, False, 2),        # FPN lateral: nearest-2x upsampled top-down add
+    ("s_k256_n512_s2", 1, 256, 24, 36, 512, 2, False, 0),        # stride-2 shortcut (res3.0)
+    ("s_k64_n128", 3, 64, 9, 11, 128, 1, True, 0),               # a single chunk
+]
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", STREAM_CASES, ids=[c[0] for c in STREAM_CASES])
+def test_conv1x1_stream(case, prec, logdir):
+    """conv1x1_stream (cfg 9): f32 against torch CPU f32 AND bit-for-bit against the tiled kernel (same MFMA chain, same k
+    order); 16-bit storage modes within one ulp of the storage type of the rounded f32 reference."""
+    from hip_helpers import hip_conv2d, err_stats
+    import zlib
+    name, B, Cin, H, W, Cout, stride, relu, res_mode = case
+    if prec == 0 and Cin != 64:
+        pytest.skip("f32 operands: the streaming kernel holds K = 64 only (128 A registers otherwise); tiled kernel used")
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    dt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[prec]
+    r16 = lambda t: t.to(dt).to(torch.float32)
+    x = r16(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, r16(w), b, stride=stride)
+    res = None
+    if res_mode == 1:
+        res = r16(torch.randn(ref.shape, generator=g))
+        ref = ref + res
+    elif res_mode == 2:
+        res = r16(torch.randn(B, Cout, ref.shape[2] // 2, ref.shape[3] // 2, generator=g))
+        ref = ref + F.interpolate(res, scale_factor=2, mode="nearest")
+    if relu:
+        ref = F.relu(ref)
+    kw = dict(prec=prec, x_st=prec, res_st=prec if res is not None else 0, y_st=prec)
+    out = hip_conv2d(x, w, b, stride, 0, relu, res, res_mode, 9, 0, **kw)
+    tiled = hip_conv2d(x, w, b, stride, 0, relu, res, res_mode, 0, 0, **kw)
+    assert int(torch.isnan(out).sum()) == 0
+    if prec == 0:
+        st = err_stats(out, ref)
+        _log(logdir, "conv_stream/f32/" + name, dict(st, equal_to_tiled=bool(torch.equal(out, tiled))))
+        assert st["rel_to_max"] < 2e-5, st
+        assert torch.equal(out, tiled)
+    else:
+        ulp = 2.0 ** (-7 if prec == 1 else -10)
+        diff = (out - r16(ref)).abs()
+        tol = ulp * ref.abs().clamp_min(1e-3) * 1.01 + 1e-6
+        frac = float((diff > 1e-6 * ref.abs().clamp_min(1.0)).float().mean())
+        same = float((out == tiled).float().mean())
+        _log(logdir, "conv_stream/%d/" % prec + name, dict(max=float(diff.max()), frac_differs=frac, equal_to_tiled_frac=same))
+        assert bool((diff <= tol).all()) and frac < 0.02
+        assert same > 0.98                      # same chain up to the order of the bias / residual adds
+
+
+def test_conv1x1_stream_refuses_ineligible_layers():
+    """cfg 9 on a layer the streaming kernel does not take (3x3, K = 512, narrow N) is an error, never a silent fallback."""
+    from apse_uav_amd import _lib
+    lib = _lib.load()
+    for (cin, cout, k) in ((64, 256, 3), (512, 256, 1), (64, 64, 1)):
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad = 1, 8, 8, cin, cout, k, k, 1, k // 2
+        d.cfg = 9
+        x = torch.zeros(1, 8, 8, cin, device="cuda")
+        wp = torch.zeros(lib.apse_conv_packed_elems(C.byref(d)), device="cuda")
+        y = torch.zeros(1, 8, 8, cout, device="cuda")
+        ws = torch.zeros(16, device="cuda")
+        assert lib.apse_conv2d(C.byref(d), _lib.ptr(x), _lib.ptr(wp), None, None, _lib.ptr(y), _lib.ptr(ws), 64, _lib.stream_ptr()) != 0
+
+
 def test_maxpool(logdir):
     from apse_uav_amd import _lib
     from hip_helpers import to_nhwc
