@@ -666,11 +666,24 @@ static int launch_cfg_k2(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hip
     return descriptor_ok(p) ? launch_cfg_x<WM, WN, TM, TN, KS, 0, 2>(p, s, ev0, ev1) : launch_cfg_x<WM, WN, TM, TN, KSF, 1>(p, s, ev0, ev1);
 }
 
+int apse_conv_effective_cfg(const ConvParams& p, int cfg) {
+    // an explicit request for a streaming kernel is honoured only when the layer is eligible (-1 otherwise: an error, never a
+    // silent launch on a shape the kernel does not handle)
+    if (cfg == APSE_CFG_STREAM) return (!p.no_stream && apse_conv1x1_stream_ok(p)) ? APSE_CFG_STREAM : -1;
+    if (cfg == APSE_CFG_STREAM_K) return (!p.no_stream && apse_conv1x1_stream_k_ok(p)) ? APSE_CFG_STREAM_K : -1;
+    if (p.no_stream) return cfg;
+    if (apse_conv1x1_stream_ok(p)) return APSE_CFG_STREAM;
+    if (p.stream_k && apse_conv1x1_stream_k_ok(p)) return APSE_CFG_STREAM_K;
+    return cfg;
+}
+
 int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (p.M <= 0 || p.Cout <= 0 || p.steps_total <= 0) return APSE_E_INVALID;
     if (p.res_mode != 0 && (p.Cout & 3) != 0) return APSE_E_INVALID;      // residual rows are read as float4
-    if (cfg == APSE_CFG_STREAM && (p.no_stream || !apse_conv1x1_stream_ok(p))) return APSE_E_INVALID;
-    if (!p.no_stream && apse_conv1x1_stream_ok(p)) return apse_launch_conv1x1_stream(p, s, ev0, ev1);
+    const int eff = apse_conv_effective_cfg(p, cfg);
+    if (eff < 0) return APSE_E_INVALID;                                   // a streaming kernel asked for, layer not eligible
+    if (eff == APSE_CFG_STREAM) return apse_launch_conv1x1_stream(p, s, ev0, ev1);
+    if (eff == APSE_CFG_STREAM_K) return apse_launch_conv1x1_stream_k(p, s, ev0, ev1);
     if (p.prec == 1 || p.prec == 2) {
         // operands already stored 16-bit, filter rows a whole number of 64-element steps: the scheduled kernel
         const bool fast16 = p.w16 && p.x_st == p.prec && (p.KWCp & 63) == 0 && p.cin_log2 >= 3 &&

@@ -317,6 +317,8 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     const int Mfull = c->cfg.max_batch * in_items_mult * p.OH * p.OW;
     int sk = 1;
     cs.cfg = apse_conv_pick_cfg(Mfull, Cout, p.steps_total, &sk);
+    // 1x1 layers of K > 256: the streamed-A kernel (conv1x1_stream_k) does not beat the tiled kernel yet: off
+    p.stream_k = 0;
     if (count_kind == 2) {
         // GEMMs over the packed detection list: the tile shape and the K split fix the f32 summation order, so they are
         // chosen HERE, once, from plan constants only (a typical list of APSE_EXPECTED_DETS detections; never from
@@ -382,7 +384,7 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
             }
             if (c->prof_on && c->ev_used + 2 <= (int)c->ev_pool.size()) { e0 = c->ev_used; c->ev_used += 2; }
             rc = apse_launch_conv(p, cfg, s, e0 >= 0 ? c->ev_pool[e0] : nullptr, e0 >= 0 ? c->ev_pool[e0 + 1] : nullptr);
-            if (apse_conv1x1_stream_ok(p)) cfg = APSE_CFG_STREAM;             // profile label of the kernel that actually ran
+            cfg = apse_conv_effective_cfg(p, cfg);                            // profile label of the kernel that actually ran
             if (e0 >= 0) c->pending.push_back({cfg, st.c.flops_per_item, st.c.count_kind, st.c.b_mult, batch, e0, e0 + 1});
         } else if (st.kind == S_MAXPOOL) {
             rc = apse_k_maxpool3x3s2(st.x, st.y, batch, st.H, st.W, st.C, st.st, s);
@@ -966,9 +968,9 @@ int apse_profile(apse_ctx* c, int enable) {
     return APSE_OK;
 }
 
-int apse_profile_read(apse_ctx* c, double* out30, int reset) {
-    if (!c || !out30) return APSE_E_INVALID;
-    memcpy(out30, c->prof, sizeof(c->prof));
+int apse_profile_read(apse_ctx* c, double* out33, int reset) {
+    if (!c || !out33) return APSE_E_INVALID;
+    memcpy(out33, c->prof, sizeof(c->prof));
     if (reset) memset(c->prof, 0, sizeof(c->prof));
     return APSE_OK;
 }
@@ -1116,11 +1118,12 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
     if (p.x_st && cin_p < 8) return APSE_E_INVALID;
     int sk = 1;
     int cfg = apse_conv_pick_cfg(p.M, p.Cout, p.steps_total, &sk);
-    if (d->cfg >= 0) { cfg = d->cfg; sk = 1; p.no_stream = (d->cfg != APSE_CFG_STREAM); }
+    if (d->cfg >= 0) { cfg = d->cfg; sk = 1; p.no_stream = (d->cfg != APSE_CFG_STREAM && d->cfg != APSE_CFG_STREAM_K); }
     if (d->splitk > 0) sk = d->splitk;
     if (sk > p.steps_total) sk = p.steps_total;
     p.splitk = sk;
     if (sk > 1 && (size_t)sk * p.M * p.Cout * sizeof(float) > ws_bytes) return APSE_E_INVALID;
+    p.stream_k = 0;
     if (sk > 1 && d->fuse_reduce) {
         static int* cnt = nullptr;
         if (!cnt) { if (hipMalloc(reinterpret_cast<void**>(&cnt), 65536 * sizeof(int)) != hipSuccess) return APSE_E_NOMEM; hipMemset(cnt, 0, 65536 * sizeof(int)); }

@@ -175,7 +175,7 @@ def explain_detection_sets(A, B, score_thr=0.5, nms_thr=0.5, match_iou=0.9):
     return explain_sets(_flat_box_side(A), _flat_box_side(B), score_thr, nms_thr, match_iou=match_iou, noise_floor=0.3)
 
 
-def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise_floor=None):
+def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise_floor=None, pre_topk=None):
     """Compares what two runs of one selection stage keep (HIP vs oracle, f32 vs 16-bit, ...).
 
     A side = dict(cand_boxes [n,4], cand_scores [n], cand_cat [n]  -- every candidate the stage ranks (category = class
@@ -189,7 +189,11 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
       (score) its score there is on the other side of score_thr, within eps_score of the kept one, or
       (nms)   it was suppressed there by a kept item with IoU u > nms_thr while the same pair has IoU <= nms_thr in the
               run that keeps it, and the two IoUs differ by at most eps_iou, or
-      (rank)  it falls past the top-``rank_limit`` cut there with a score within eps_score of that run's last kept one.
+      (rank)  it falls past the top-``rank_limit`` cut there with a score within eps_score of that run's last kept one, or
+      (swap)  it was suppressed there by an item q only that run keeps, and the two runs ORDER p and q differently (greedy NMS
+              keeps the better-scored of an overlapping pair) with both score changes within eps_score, or
+      (top-k) the other run does not even rank it: its category's candidate list is full (``pre_topk``) and ends within
+              eps_score of this item's score (the per-level pre-NMS cut of the RPN).
     "Within eps" means within BAND x the largest deviation seen on the other candidates (BAND = 1.5: the disputed item is
     one more draw from the same noise, and the maximum of ~10^2 draws is exceeded by a fresh one about once in 10^2).
     Everything else -- including "the other run has no such candidate" -- is returned in ``unexplained``."""
@@ -268,31 +272,71 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
         yb, ys, yc = Y["cand_boxes"], Y["cand_scores"], Y["cand_cat"]
         sel = (yc == cat).nonzero()[:, 0]
         uu = _iou_matrix(box[None], yb[sel])[0] if sel.numel() else torch.zeros(0, dtype=torch.double)
+        far = _iou_matrix(box[None], pair_box)[0] < 0.5 if pair_box.shape[0] else torch.zeros(0, dtype=torch.bool)
+        eps_here = float(pair_ds[far].max()) if int(far.sum()) else 0.0       # score noise of the other candidates
+        if sel.numel() and float(uu.max()) < match_iou:
+            # noisy runs (bf16 moves small boxes by several pixels): the same candidate may fall below match_iou.  Accept one
+            # that still overlaps by >= 0.7 AND carries the same score within the measured score noise
+            near = (uu >= 0.7) & ((ys[sel] - s).abs() <= max(BAND * eps_here, 1e-6))
+            if bool(near.any()):
+                k2 = int(torch.where(near, uu, torch.zeros_like(uu)).argmax())
+                c2 = sel[k2]
+                kk = (Y["cats"] == cat).nonzero()[:, 0]
+                if kk.numel() and float(_iou_matrix(yb[c2][None], Y["boxes"][kk])[0].max()) >= 0.99:
+                    item.update(why="kept in both runs: the same candidate (score within the noise), its box moved to IoU %.3f under the box noise"
+                                    % float(uu[k2]), other_score=float(ys[c2]))
+                    return item, True
         if not sel.numel() or float(uu.max()) < match_iou:
             item["why"] = "no counterpart candidate in the other run"
             item["best_iou_in_other"] = round(float(uu.max()), 4) if sel.numel() else 0.0
+            if pre_topk is not None and int(sel.numel()) >= pre_topk:
+                cut = float(ys[sel].min())                       # the other run's list of this category is full and ends here
+                item.update(why="pre-NMS top-k cut", other_cut_score=cut, margin_to_cut=round(s - cut, 6),
+                            eps_score_of_the_others=round(eps_here, 6))
+                return item, (s - cut) <= max(BAND * eps_here, 1e-6)
             return item, False
         c = sel[int(uu.argmax())]
         sy = float(ys[c])
-        far = _iou_matrix(box[None], pair_box)[0] < 0.5 if pair_box.shape[0] else torch.zeros(0, dtype=torch.bool)
-        eps_here = float(pair_ds[far].max()) if int(far.sum()) else 0.0       # score noise of the other candidates
         item.update(other_score=sy, score_diff=round(abs(s - sy), 6), eps_score_of_the_others=round(eps_here, 6))
         if score_thr is not None:
             item.update(score_margin_to_thr=round(s - score_thr, 6), other_margin_to_thr=round(sy - score_thr, 6))
             if sy <= score_thr:
                 item["why"] = "score threshold"
                 return item, abs(s - sy) <= max(BAND * eps_here, 1e-6)
-        # a live candidate in Y that Y does not keep: suppressed by a kept item of its category, or past the rank cut
-        ksel = (Y["cats"] == cat).nonzero()[:, 0]
+        # a live candidate in Y that Y does not keep: suppressed by a BETTER-scored kept item of its category (greedy NMS), or
+        # past the rank cut
+        ksel = ((Y["cats"] == cat) & (Y["scores"] >= sy)).nonzero()[:, 0]
         u_y, j = 0.0, -1
         if ksel.numel():
             uy = _iou_matrix(yb[c][None], Y["boxes"][ksel])[0]
             j = int(ksel[int(uy.argmax())])
             u_y = float(uy.max())
+        if u_y <= nms_thr:
+            # no better-scored suppressor: look for a kept item that overlaps it and scores (slightly) LOWER in Y's own ranking
+            ksel2 = (Y["cats"] == cat).nonzero()[:, 0]
+            if ksel2.numel():
+                uy2 = _iou_matrix(yb[c][None], Y["boxes"][ksel2])[0]
+                if float(uy2.max()) > nms_thr:
+                    j = int(ksel2[int(uy2.argmax())])
+                    u_y = float(uy2.max())
         if u_y > nms_thr:
             jx = pair_of.get(j)
             item.update(why="nms", iou_in_other=round(u_y, 6), nms_margin_other=round(u_y - nms_thr, 6))
             if jx is None:
+                # the suppressor q is itself an item only the other run keeps.  Either the two runs order p and q differently
+                # (near-tied scores: greedy NMS keeps whichever ranks first) ...
+                qb = Y["boxes"][j]
+                xsel = (X["cand_cat"] == cat).nonzero()[:, 0]
+                uq = _iou_matrix(qb[None], X["cand_boxes"][xsel])[0] if xsel.numel() else torch.zeros(0, dtype=torch.double)
+                if xsel.numel() and float(uq.max()) >= match_iou:
+                    sq_x = float(X["cand_scores"][xsel[int(uq.argmax())]])
+                    sq_y = float(Y["scores"][j])
+                    item.update(q_score_here=sq_x, q_score_other=sq_y)
+                    if sq_x <= s and sq_y >= sy and abs(s - sy) <= max(BAND * eps_here, 1e-6) and abs(sq_x - sq_y) <= max(BAND * eps_here, 1e-6):
+                        item["why"] = "order swap: the runs rank this item and its overlapping rival differently, both score changes inside the noise"
+                        return item, True
+                # ... or q's presence there is a disagreement of its own: resolved below once every direct case is known
+                item["suppressor_only_in_other"] = j
                 return item, False
             u_x = float(_iou_matrix(box[None], X["boxes"][jx][None])[0, 0])
             other = _iou_matrix(box[None], sub_box)[0] < match_iou if sub_box.shape[0] else torch.zeros(0, dtype=torch.bool)
@@ -313,18 +357,32 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
         item, good = explain(A, B, i, "A", a_of_b)
         item["explained"] = bool(good)
         rep["only"].append(item)
-        if not good:
-            unexplained.append(item)
     for j in onlyB:
         item, good = explain(B, A, j, "B", b_of_a)
         item["explained"] = bool(good)
         rep["only"].append(item)
-        if not good:
-            unexplained.append(item)
+    # NMS cascades: X keeps p, Y suppressed p with q, and q is something only Y keeps.  Had q been suppressed in Y too (as it
+    # is in X), p would have survived there: p's disagreement is a consequence of q's, so it stands or falls with it.
+    by_key = {(o["side"], o["index"]): o for o in rep["only"]}
+    changed = True
+    while changed:
+        changed = False
+        for o in rep["only"]:
+            if o["explained"] or "suppressor_only_in_other" not in o:
+                continue
+            q = by_key.get(("B" if o["side"] == "A" else "A", o["suppressor_only_in_other"]))
+            if q is not None and q["explained"]:
+                o["explained"] = True
+                o["why"] = "nms cascade: suppressed in the other run by an item only that run keeps (whose presence is explained)"
+                changed = True
+    unexplained = [o for o in rep["only"] if not o["explained"]]
+    rep["n_only"] = len(rep["only"])
+    rep["n_direct"] = sum(1 for o in rep["only"] if o["explained"] and not o["why"].startswith("nms cascade"))
+    rep["n_cascade"] = sum(1 for o in rep["only"] if o["explained"] and o["why"].startswith("nms cascade"))
     return rep, unexplained
 
 
-def explain_frame(hip_model, post, logf=None, b=0):
+def explain_frame(hip_model, post, dump=None, b=0):
     """Both selection stages of one frame, HIP (side A) vs an oracle run (side B).  A box-branch item whose only problem
     is "no counterpart candidate" is traced to its PROPOSAL: if the other run lacks that proposal and the RPN-stage
     analysis explains the proposal's absence (NMS at 0.7 / rank cut inside the measured noise), the item is explained too."""
@@ -332,22 +390,48 @@ def explain_frame(hip_model, post, logf=None, b=0):
     rep_box, un_box = explain_detection_sets(hb, ob)
     hr, orr = hip_rpn_side(hip_model, b), oracle_rpn_side(post)
     post_topk = int(hip_model._cfg_c.rpn_post_topk)
-    rep_rpn, un_rpn = explain_sets(hr, orr, None, float(hip_model._cfg_c.rpn_nms), rank_limit=post_topk)
+    rep_rpn, un_rpn = explain_sets(hr, orr, None, float(hip_model._cfg_c.rpn_nms), rank_limit=post_topk,
+                                   pre_topk=int(hip_model._cfg_c.rpn_pre_topk))
     res = hip_model.last_results
     lo, hi = res.image_slice(b)
     roi = {"A": torch.from_numpy(res.roi[lo:hi].astype(np.int64)), "B": post["box_det"]["roi_index"]}
     props = {"A": hr["boxes"], "B": orr["boxes"]}
     explained_rpn = {(o["side"], o["index"]) for o in rep_rpn["only"] if o["explained"]}
     still = []
+
+    def fpn_level(b):          # detectron2 assign_boxes_to_levels: floor(4 + log2(sqrt(area) / 224 + 1e-8)), clamped to [2, 5]
+        k = 4.0 + float(torch.log2(torch.sqrt((b[2] - b[0]) * (b[3] - b[1])) / 224.0 + 1e-8))
+        return k, int(min(max(np.floor(k), 2), 5))
+
     for item in un_box:
         if item["why"].startswith("no counterpart"):
             side = item["side"]
+            other = "B" if side == "A" else "A"
             r = int(roi[side][item["index"]])
+            pb = props[side][r]
             item["proposal_index"] = r
-            item["proposal_box"] = [round(float(v), 2) for v in props[side][r]]
+            item["proposal_box"] = [round(float(v), 2) for v in pb]
             if (side, r) in explained_rpn:
                 item["why"] = "its proposal is absent from the other run; the RPN-stage analysis explains that absence"
                 item["explained"] = True
                 continue
+            # the proposal exists in both runs: does it pool from a different pyramid level there?  (a discrete decision:
+            # sqrt(area) / 224 at a power of two)
+            uo = _iou_matrix(pb[None], props[other])[0]
+            if props[other].shape[0] and float(uo.max()) >= 0.7:
+                po = props[other][int(uo.argmax())]
+                k_here, l_here = fpn_level(pb)
+                k_other, l_other = fpn_level(po)
+                item.update(proposal_level_here=l_here, proposal_level_other=l_other, level_k_here=round(k_here, 5), level_k_other=round(k_other, 5))
+                if l_here != l_other and abs(k_here - k_other) < 0.05:
+                    item["why"] = ("its proposal is pooled from pyramid level %d here and %d there: sqrt(area)/224 sits on a power of two, "
+                                   "the box noise decides the floor()" % (l_here, l_other))
+                    item["explained"] = True
+                    continue
         still.append(item)
+    if dump:
+        import json
+        with open(dump, "w") as f:
+            json.dump(dict(box=rep_box, rpn=rep_rpn), f, indent=1)
+    rep_rpn = dict(rep_rpn, only=rep_rpn["only"][:6] + ([{"truncated": len(rep_rpn["only"]) - 6}] if len(rep_rpn["only"]) > 6 else []))
     return dict(box=rep_box, rpn=rep_rpn), still + un_rpn
