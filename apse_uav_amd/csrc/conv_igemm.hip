@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvPa
     constexpr int BP = BN / SR;
     static_assert(AP >= 1 && BP >= 1 && KS % WK == 0 && (DESC || WK == 1), "unsupported shape");
     constexpr int LDC = BN + 4;
-    constexpr bool DP = DESC && (TM * TN <= 2);
+    constexpr bool DP = DESC && (TM * TN <= 2 || (PR != 0 && WM * WN == 8 && APSE_DP16));      // 16-bit big tiles: a second register set (fetch two k-steps ahead) where the budget allows
     constexpr int NSET = DP ? 2 : 1;
     constexpr int STORE_AT = 4 * KS - 2;          // chunk before which the next k-slice is written to LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];

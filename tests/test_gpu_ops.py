@@ -317,6 +317,9 @@ def test_roi_align_parity(logdir):
                          (cy + bh / 2).clamp(0, 192)], dim=1)
     boxes[0] = torch.tensor([0., 0., 336., 192.])
     boxes[1] = torch.tensor([10., 10., 10.5, 10.2])
+    boxes[2] = torch.tensor([0., 80., 336., 108.])        # wide and flat on the finest level: its cell window exceeds the LDS
+    boxes[3] = torch.tensor([-20., -30., 40., 25.])       # budget of roi_align_lds (direct-load path); samples left / above the map
+    boxes[4] = torch.tensor([300., 170., 400., 260.])     # samples right of / below the map
     for R in (7, 14):
         ref = ops.roi_pooler([f[0] for f in feats], boxes, R)
         fd = [to_nhwc(f).cuda() for f in feats]
