@@ -58,11 +58,14 @@ int apse_launch_conv_bf16(const ConvParams& p, int cfg, hipStream_t s);   // con
 // conv1x1_stream.hip: the memory-streaming kernel for small-K / wide-N 1x1 layers (cfg label APSE_CFG_STREAM in profiles)
 #define APSE_CFG_STREAM 9
 #define APSE_CFG_STREAM_K 10
-#define APSE_NCFG 11
+#define APSE_CFG_GLDS 11             // conv_glds16.hip: 256x128 tile, 16-bit operands, LDS-DMA ring
+#define APSE_NCFG 12
 bool apse_conv1x1_stream_ok(const ConvParams& p);
 int apse_launch_conv1x1_stream(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 bool apse_conv1x1_stream_k_ok(const ConvParams& p);
 int apse_launch_conv1x1_stream_k(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+bool apse_conv_glds16_ok(const ConvParams& p);
+int apse_launch_conv_glds16(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // which kernel apse_launch_conv runs for (p, cfg): APSE_CFG_STREAM / APSE_CFG_STREAM_K, or cfg itself (a tiled shape)
 int apse_conv_effective_cfg(const ConvParams& p, int cfg);
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

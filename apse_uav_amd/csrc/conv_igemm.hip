@@ -666,14 +666,31 @@ static int launch_cfg_k2(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hip
     return descriptor_ok(p) ? launch_cfg_x<WM, WN, TM, TN, KS, 0, 2>(p, s, ev0, ev1) : launch_cfg_x<WM, WN, TM, TN, KSF, 1>(p, s, ev0, ev1);
 }
 
+// 16-bit operands already stored in the operand type, filter rows a whole number of 64-element steps: the scheduled kernel's
+// shape for tile config `cfg` (0 128x128, 1 64x64, 3 128x64, 6 64x64 8 waves, 8 256x128), or -1 (legacy conv_igemm_bf16 path)
+static int fast16_shape(const ConvParams& p, int cfg) {
+    const bool fast16 = (p.prec == 1 || p.prec == 2) && p.w16 && p.x_st == p.prec && (p.KWCp & 63) == 0 && p.cin_log2 >= 3 &&
+                        ((((size_t)p.B * p.H * p.W) << p.cin_log2) * 2 < 0xfffffff0ull) && !p.tile_cnt;
+    if (!fast16) return -1;
+    int c16 = (cfg == 4 || cfg == 5 || cfg == 2) ? 1 : (cfg == 7 ? 6 : cfg);
+    // deep-K layers with at least one 256x128 tile per CU: the wider tile halves the filter traffic per FLOP
+    // (out2 / rpn_t2 / res4 3x3 at batch 8: +5..7 %)
+    if (c16 == 0 && p.steps_total >= 32 && ((p.M + 255) / 256) * ((p.Cout + 127) / 128) >= 250) c16 = 8;
+    return c16;
+}
+
 int apse_conv_effective_cfg(const ConvParams& p, int cfg) {
-    // an explicit request for a streaming kernel is honoured only when the layer is eligible (-1 otherwise: an error, never a
+    // an explicit request for a special kernel is honoured only when the layer is eligible (-1 otherwise: an error, never a
     // silent launch on a shape the kernel does not handle)
     if (cfg == APSE_CFG_STREAM) return (!p.no_stream && apse_conv1x1_stream_ok(p)) ? APSE_CFG_STREAM : -1;
     if (cfg == APSE_CFG_STREAM_K) return (!p.no_stream && apse_conv1x1_stream_k_ok(p)) ? APSE_CFG_STREAM_K : -1;
-    if (p.no_stream) return cfg;
-    if (apse_conv1x1_stream_ok(p)) return APSE_CFG_STREAM;
-    if (p.stream_k && apse_conv1x1_stream_k_ok(p)) return APSE_CFG_STREAM_K;
+    if (cfg == APSE_CFG_GLDS) return apse_conv_glds16_ok(p) ? APSE_CFG_GLDS : -1;
+    if (!p.no_stream) {
+        if (apse_conv1x1_stream_ok(p)) return APSE_CFG_STREAM;
+        if (p.stream_k && apse_conv1x1_stream_k_ok(p)) return APSE_CFG_STREAM_K;
+    }
+    // wherever the 16-bit path would take the register-staged 256x128 tile, the LDS-DMA kernel of the same tile runs instead
+    if (!p.no_stream && fast16_shape(p, cfg) == 8 && apse_conv_glds16_ok(p)) return APSE_CFG_GLDS;     // (a caller forcing cfg 8 keeps the register-staged tile)
     return cfg;
 }
 
@@ -684,16 +701,11 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0
     if (eff < 0) return APSE_E_INVALID;                                   // a streaming kernel asked for, layer not eligible
     if (eff == APSE_CFG_STREAM) return apse_launch_conv1x1_stream(p, s, ev0, ev1);
     if (eff == APSE_CFG_STREAM_K) return apse_launch_conv1x1_stream_k(p, s, ev0, ev1);
+    if (eff == APSE_CFG_GLDS) return apse_launch_conv_glds16(p, s, ev0, ev1);
     if (p.prec == 1 || p.prec == 2) {
-        // operands already stored 16-bit, filter rows a whole number of 64-element steps: the scheduled kernel
-        const bool fast16 = p.w16 && p.x_st == p.prec && (p.KWCp & 63) == 0 && p.cin_log2 >= 3 &&
-                            ((((size_t)p.B * p.H * p.W) << p.cin_log2) * 2 < 0xfffffff0ull) && !p.tile_cnt;
-        if (fast16) {
+        const int c16 = fast16_shape(p, cfg);
+        if (c16 >= 0) {
             int rc = APSE_E_INVALID;
-            int c16 = (cfg == 4 || cfg == 5 || cfg == 2) ? 1 : (cfg == 7 ? 6 : cfg);
-            // deep-K layers with at least one 256x128 tile per CU: the wider tile halves the filter traffic per FLOP
-            // (out2 / rpn_t2 / res4 3x3 at batch 8: +5..7 %)
-            if (c16 == 0 && p.steps_total >= 32 && ((p.M + 255) / 256) * ((p.Cout + 127) / 128) >= 250) c16 = 8;
             if (p.prec == 1) {
                 if (c16 == 0) rc = launch_cfg_x<2, 2, 2, 2, 1, 0, 1, 1>(p, s, ev0, ev1);
                 else if (c16 == 1) rc = launch_cfg_x<2, 2, 1, 1, 2, 0, 1, 1>(p, s, ev0, ev1);

@@ -968,9 +968,9 @@ int apse_profile(apse_ctx* c, int enable) {
     return APSE_OK;
 }
 
-int apse_profile_read(apse_ctx* c, double* out33, int reset) {
-    if (!c || !out33) return APSE_E_INVALID;
-    memcpy(out33, c->prof, sizeof(c->prof));
+int apse_profile_read(apse_ctx* c, double* out36, int reset) {
+    if (!c || !out36) return APSE_E_INVALID;
+    memcpy(out36, c->prof, sizeof(c->prof));
     if (reset) memset(c->prof, 0, sizeof(c->prof));
     return APSE_OK;
 }
@@ -1118,7 +1118,7 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
     if (p.x_st && cin_p < 8) return APSE_E_INVALID;
     int sk = 1;
     int cfg = apse_conv_pick_cfg(p.M, p.Cout, p.steps_total, &sk);
-    if (d->cfg >= 0) { cfg = d->cfg; sk = 1; p.no_stream = (d->cfg != APSE_CFG_STREAM && d->cfg != APSE_CFG_STREAM_K); }
+    if (d->cfg >= 0) { cfg = d->cfg; sk = 1; p.no_stream = (d->cfg != APSE_CFG_STREAM && d->cfg != APSE_CFG_STREAM_K && d->cfg != APSE_CFG_GLDS); }
     if (d->splitk > 0) sk = d->splitk;
     if (sk > p.steps_total) sk = p.steps_total;
     p.splitk = sk;

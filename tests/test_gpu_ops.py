@@ -47,6 +47,15 @@ CONV_CASES = [
     # 256x128 tile (8 waves as 4x2; 16-bit operands only -- the f32 path maps it to 128x128): ragged M, two n tiles, residual
     ("t256x128", 1, 128, 40, 52, 256, 3, 1, 1, True, 1, 8, 0),
     ("t256x128_1x1", 2, 256, 33, 31, 384, 1, 1, 0, False, 0, 8, 0),
+    # conv_glds16 (cfg 11: the LDS-DMA 256x128 kernel; 16-bit stored operands only): 3x3 with padding taps on every border and a
+    # ragged last tile, one / two / many 64-deep stages, stride 2, both residual forms, Cout not a multiple of the tile
+    ("g_3x3_c64", 1, 64, 30, 44, 64, 3, 1, 1, True, 1, 11, 0),
+    ("g_3x3_c256", 2, 256, 21, 19, 256, 3, 1, 1, True, 0, 11, 0),
+    ("g_1x1_k64", 1, 64, 17, 23, 128, 1, 1, 0, False, 0, 11, 0),
+    ("g_1x1_k128", 1, 128, 16, 24, 200, 1, 1, 0, True, 2, 11, 0),
+    ("g_3x3_s2", 1, 128, 27, 33, 136, 3, 2, 1, False, 0, 11, 0),
+    ("g_fc7x7", 37, 256, 7, 7, 1024, 7, 1, 0, True, 0, 11, 0),
+    ("g_wide_256x256", 1, 64, 361, 359, 256, 3, 1, 1, True, 1, 11, 0),      # >= 500 tiles of 256x256: the two-stage wide-tile variant
 ]
 
 
@@ -54,6 +63,8 @@ CONV_CASES = [
 def test_conv2d_parity(case, logdir):
     from hip_helpers import hip_conv2d, err_stats
     name, B, Cin, H, W, Cout, K, stride, pad, relu, res_mode, cfg, splitk = case
+    if cfg == 11:
+        pytest.skip("conv_glds16 takes 16-bit stored operands only (test_conv2d_16bit_storage)")
     import zlib
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -84,6 +95,8 @@ def test_conv2d_bf16_parity(case, prec, logdir):
     from hip_helpers import hip_conv2d, err_stats
     import zlib
     name, B, Cin, H, W, Cout, K, stride, pad, relu, res_mode, cfg, splitk = case
+    if cfg == 11:
+        pytest.skip("conv_glds16 takes 16-bit stored operands only (test_conv2d_16bit_storage)")
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5

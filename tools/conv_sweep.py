@@ -46,11 +46,11 @@ for (name, B, H, W, Cin, Cout, K, st, pad) in SHAPES:
     rsd = torch.randn(B, OH, OW, Cout, device=dev).to(tdt) if RES else None
     ws = torch.empty(16 * M * Cout + 16, device=dev)
     res = []
-    for cfg in ((0, 1, 3, 6, 8, 9, 10) if (PREC and ST16) else (0, 1, 3, 6) if PREC else (0, 1, 2, 3, 4, 5, 6, 7, 9)):
+    for cfg in ((0, 1, 3, 6, 8, 9, 10, 11) if (PREC and ST16) else (0, 1, 3, 6) if PREC else (0, 1, 2, 3, 4, 5, 6, 7, 9)):
         if cfg in (0, 8) and Cout < 128:
             continue
         for sk in (1, 2, 3, 4, 6, 8, 16):
-            if cfg in (9, 10) and sk > 1:
+            if cfg in (9, 10, 11) and sk > 1:
                 continue
             d.cfg, d.splitk = cfg, sk
             steps = K * ((K * Cin + 31) // 32)
