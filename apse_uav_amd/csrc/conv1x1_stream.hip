@@ -472,7 +472,7 @@ bool apse_conv1x1_stream_ok(const ConvParams& p) {
     if ((((size_t)p.B * p.H * p.W) << p.cin_log2) * (p.prec ? 2 : 4) >= 0xfffffff0ull) return false;
     // residual and output live in the operand's storage type (f32 mode: f32; 16-bit modes with 16-bit storage: that type)
     if (p.y_st != p.prec || (p.res_mode != 0 && p.res_st != p.prec)) return false;
-    if (p.prec == 0) return p.x_st == 0 && p.w != nullptr && K == 64;         // f32: wider K would need 64+ more A / residual registers
+    if (p.prec == 0) return p.x_st == 0 && p.w != nullptr && K == 64;         // f32, K = 128 / 256 (one wave per SIMD): measured equal to the tiled kernel, not used
     return p.x_st == p.prec && p.w16 != nullptr;
 }
 

@@ -23,9 +23,9 @@ struct PasteParams {
     int words_per_row; float thresh; float* boxes_out; int* valid; int* rect; uint64_t* bits; unsigned long long* sums;
 };
 extern "C" {
-int apse_k_pil_resize(const uint8_t*, uint8_t*, float*, uint8_t*, const int*, const int*, int, const int*, const int*, int, int,
+int apse_k_pil_resize(const uint8_t*, uint8_t*, void*, int, uint8_t*, const int*, const int*, int, const int*, const int*, int, int,
                       int, int, int, int, int, int, const float*, hipStream_t);
-int apse_k_chw_norm(const float*, float*, int, int, int, int, int, const float*, hipStream_t);
+int apse_k_chw_norm(const float*, void*, int, int, int, int, int, int, const float*, hipStream_t);
 int apse_k_maxpool3x3s2(const void*, void*, int, int, int, int, int, hipStream_t);
 int apse_k_subsample2(const void*, void*, int, int, int, int, int, hipStream_t);
 int apse_k_nhwc_to_nchw(const void*, float*, int, int, int, int, hipStream_t);
@@ -176,6 +176,7 @@ struct ConvSpec {
     int KH, KW, stride, pad, relu;
     int fc_h = 0, fc_w = 0;   // >0: weight is [Cout][C*fc_h*fc_w] flattened (c,h,w): treat as fc_h x fc_w valid conv
     int deconv = 0;
+    int s2d = 0;              // stem on the space-to-depth(2) input: the 7x7 / stride-2 filter is re-indexed as 4x4 / stride-1 over 12 channels
 };
 
 // 16-bit storage mode: every activation the bulk GEMMs produce lives in HBM in the operand type; the narrow
@@ -226,6 +227,23 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
                             oihw[((size_t)((dy * 2 + dx) * cc + o)) * ci + i] = w->v[(((size_t)i * cc + o) * 2 + dy) * 2 + dx];
         } else if (w->shape.size() == 2) {
             co = (int)w->shape[0]; ci = (int)w->shape[1]; oihw = w->v;
+        } else if (sp.s2d) {
+            // out(oy, ox) = sum w7[ky][kx][c] x[2 oy - 3 + ky][2 ox - 3 + kx][c]; with input row 2 Y + dy, Y = oy - 2 + r (r = 0..3):
+            // ky = 2 r + dy - 1, kx = 2 s + dx - 1 (taps outside 0..6 do not exist: zero), channel (2 dy + dx) 3 + c
+            if (w->shape.size() != 4 || w->shape[2] != 7 || w->shape[3] != 7 || w->shape[1] != 3 || KH != 4 || KW != 4)
+                return fail(c, APSE_E_INVALID, "space-to-depth stem needs a 7x7 filter over 3 channels: " + wn);
+            co = (int)w->shape[0]; ci = 12;
+            oihw.assign((size_t)co * 12 * 16, 0.f);
+            for (int o = 0; o < co; ++o)
+                for (int ch = 0; ch < 3; ++ch)
+                    for (int r = 0; r < 4; ++r)
+                        for (int sx = 0; sx < 4; ++sx)
+                            for (int dy = 0; dy < 2; ++dy)
+                                for (int dx = 0; dx < 2; ++dx) {
+                                    const int ky = 2 * r + dy - 1, kx = 2 * sx + dx - 1;
+                                    if (ky < 0 || ky > 6 || kx < 0 || kx > 6) continue;
+                                    oihw[(((size_t)o * 12 + (dy * 2 + dx) * 3 + ch) * 4 + r) * 4 + sx] = w->v[(((size_t)o * 3 + ch) * 7 + ky) * 7 + kx];
+                                }
         } else {
             co = (int)w->shape[0]; ci = (int)w->shape[1]; oihw = w->v;
             if ((int)w->shape[2] != KH || (int)w->shape[3] != KW) return fail(c, APSE_E_INVALID, "kernel size mismatch " + wn);
@@ -260,6 +278,7 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     }
     const int cin_p = in.C;
     if (pow2_at_least(Cin) != cin_p && Cin != cin_p) return fail(c, APSE_E_INVALID, "input channels mismatch at " + sp.name);
+    if (sp.s2d && (in.C != 16 || sp.stride != 1 || sp.pad != 2)) return fail(c, APSE_E_INVALID, "space-to-depth stem geometry");
     const int KWC = KW * cin_p, KWCp = apse_roundup(KWC, 32);
     const int Cout_p = apse_roundup(Cout, 128);
     std::vector<float> packed((size_t)Cout_p * KH * KWCp, 0.f);
@@ -294,6 +313,7 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     p.KH = KH; p.KW = KW; p.stride = sp.stride; p.pad = sp.pad; p.KWCp = KWCp;
     p.OH = (in.H + 2 * sp.pad - KH) / sp.stride + 1;
     p.OW = (in.W + 2 * sp.pad - KW) / sp.stride + 1;
+    if (sp.s2d) { p.OH = in.H; p.OW = in.W; }       // pad 2 above / left, 1 below / right: taps past the map read zeros (range check)
     p.Cout = Cout; p.relu = sp.relu;
     p.steps_total = KH * (KWCp / 32);
     p.splitk = 1;
@@ -312,7 +332,8 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     p.y_st = o.st;
     if (!o.p) return fail(c, APSE_E_NOMEM, "activation alloc failed at " + sp.name);
     p.y = o.p; p.y_ld = out_c; p.y_coff = 0;
-    cs.flops_per_item = 2.0 * p.OH * p.OW * (double)Cout * KH * KW * Cin;
+    cs.flops_per_item = sp.s2d ? 2.0 * p.OH * p.OW * (double)Cout * 7 * 7 * 3        // algorithmic: the reference's 7x7x3 taps
+                               : 2.0 * p.OH * p.OW * (double)Cout * KH * KW * Cin;
     // tile config / split-K chosen for the full batch; workspace sized for the worst case over 1..max_batch
     const int Mfull = c->cfg.max_batch * in_items_mult * p.OH * p.OW;
     int sk = 1;
@@ -425,10 +446,20 @@ static int build_plan(apse_ctx* c) {
     if (!c->res) return fail(c, APSE_E_NOMEM, "results alloc");
     int rc;
     // ---- backbone
-    Tens x0 = make_t(c, "input", B, c->PH, c->PW, 4);
     Tens cur;
-    rc = add_conv(c, c->backbone, ConvSpec{"stem.conv1", {"backbone.bottom_up.stem.conv1"}, 7, 7, 2, 3, 1}, x0, 1, &cur,
-                  "stem.conv1", nullptr, 0, 0, 0);
+    if (storage_type(c)) {
+        // 16-bit storage modes: space-to-depth(2) input (elementwise.hip, input_store) and the stem as a 4x4 / stride-1 convolution
+        // over 16 channels: one 64-element k-step per filter row on the scheduled 16-bit kernel (K = 256 instead of the 448 a
+        // 7-pixel x 8-channel run would pad to; the f32-input stem ran on the legacy conditional-load kernel at 428 us per batch 8)
+        Tens x0 = make_t(c, "input", B, c->PH / 2, c->PW / 2, 16, storage_type(c));
+        ConvSpec sp{"stem.conv1", {"backbone.bottom_up.stem.conv1"}, 4, 4, 1, 2, 1};
+        sp.s2d = 1;
+        rc = add_conv(c, c->backbone, sp, x0, 1, &cur, "stem.conv1", nullptr, 0, 0, 0);
+    } else {
+        Tens x0 = make_t(c, "input", B, c->PH, c->PW, 4);
+        rc = add_conv(c, c->backbone, ConvSpec{"stem.conv1", {"backbone.bottom_up.stem.conv1"}, 7, 7, 2, 3, 1}, x0, 1, &cur,
+                      "stem.conv1", nullptr, 0, 0, 0);
+    }
     if (rc) return rc;
     {
         Step st; st.kind = S_MAXPOOL; st.x = cur.p; st.H = cur.H; st.W = cur.W; st.C = cur.C;
@@ -756,7 +787,7 @@ int apse_preprocess_frames(apse_ctx* c, const uint8_t* frames, int batch, void* 
     NEED_READY(c, batch);
     if (!c->hb) return fail(c, APSE_E_STATE, "resize tables not set");
     const apse_config& g = c->cfg;
-    int rc = apse_k_pil_resize(frames, c->rs_tmp, c->t["input"].p, nullptr, c->hb, c->hc, c->hk, c->vb, c->vc, c->vk, batch,
+    int rc = apse_k_pil_resize(frames, c->rs_tmp, c->t["input"].p, c->t["input"].st, nullptr, c->hb, c->hc, c->hk, c->vb, c->vc, c->vk, batch,
                                g.frame_h, g.frame_w, g.image_h, g.image_w, c->PH, c->PW, g.pixel_mean, (hipStream_t)stream);
     return rc ? fail(c, rc, "pil resize launch failed") : APSE_OK;
 }
@@ -764,7 +795,7 @@ int apse_preprocess_frames(apse_ctx* c, const uint8_t* frames, int batch, void* 
 int apse_preprocess_images(apse_ctx* c, const float* images, int batch, void* stream) {
     NEED_READY(c, batch);
     const apse_config& g = c->cfg;
-    int rc = apse_k_chw_norm(images, c->t["input"].p, batch, g.image_h, g.image_w, c->PH, c->PW, g.pixel_mean,
+    int rc = apse_k_chw_norm(images, c->t["input"].p, c->t["input"].st, batch, g.image_h, g.image_w, c->PH, c->PW, g.pixel_mean,
                              (hipStream_t)stream);
     return rc ? fail(c, rc, "chw normalise launch failed") : APSE_OK;
 }
@@ -1292,7 +1323,7 @@ int apse_undistort_gamma(const uint8_t* src, uint8_t* dst, int B, int H, int W, 
 int apse_resize_normalize(const uint8_t* frames, uint8_t* tmp, float* out, uint8_t* resized, const int* hb, const int* hc, int hk,
                           const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,
                           const float* mean3, void* stream) {
-    return apse_k_pil_resize(frames, tmp, out, resized, hb, hc, hk, vb, vc, vk, B, H, W, OH, OW, PH, PW, mean3, (hipStream_t)stream);
+    return apse_k_pil_resize(frames, tmp, out, 0, resized, hb, hc, hk, vb, vc, vk, B, H, W, OH, OW, PH, PW, mean3, (hipStream_t)stream);
 }
 
 }  // extern "C"

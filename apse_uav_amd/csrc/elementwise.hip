@@ -48,9 +48,19 @@ __global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ 
     }
 }
 
-// Vertical pass + normalise + pad: out is NHWC4 f32 [B][PH][PW][4]; only the OHxOW interior is
-// written (the pad area and channel 3 are zeroed once at allocation and never touched).
-__global__ __launch_bounds__(256) void pil_resize_v_norm(const uint8_t* __restrict__ tmp, float* __restrict__ out,
+// Network input layouts (both zeroed once at allocation; only the OH x OW interior and the 3 real channels are ever written):
+//   out_st = 0: NHWC4 f32 [B][PH][PW][4] (BGR0);
+//   out_st = 1 / 2 (16-bit storage modes): space-to-depth(2) NHWC16 bf16 / f16 [B][PH/2][PW/2][16], channel = (2 (y & 1) + (x & 1)) 3 + c:
+//     the 7x7 / stride-2 stem becomes a 4x4 / stride-1 convolution over 12 (+4 zero) channels whose filter-row run is exactly one
+//     64-element k-step of the 16-bit MFMA kernels (detector.hip, stem).  The value is rounded once, here, to the operand type
+//     (the f32-input stem kernel rounded the same value while staging).
+__device__ __forceinline__ void input_store(void* out, int out_st, int b, int oy, int ox, int c, int PH, int PW, float v) {
+    if (out_st == 0) reinterpret_cast<float*>(out)[(((size_t)b * PH + oy) * PW + ox) * 4 + c] = v;
+    else apse_st1(out, (((size_t)b * (PH >> 1) + (oy >> 1)) * (PW >> 1) + (ox >> 1)) * 16 + ((oy & 1) * 2 + (ox & 1)) * 3 + c, v, out_st);
+}
+
+// Vertical pass + normalise + pad.
+__global__ __launch_bounds__(256) void pil_resize_v_norm(const uint8_t* __restrict__ tmp, void* __restrict__ out, int out_st,
                                                          const int* __restrict__ bounds, const int* __restrict__ coef,
                                                          int OH, int OW, int ksize, int PH, int PW,
                                                          float m0, float m1, float m2, size_t tmp_img_stride,
@@ -66,20 +76,26 @@ __global__ __launch_bounds__(256) void pil_resize_v_norm(const uint8_t* __restri
     const int v = clip8(ss);
     const int ox = o / 3, c = o - ox * 3;
     const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
-    out[(((size_t)b * PH + oy) * PW + ox) * 4 + c] = (float)v - mean;
+    input_store(out, out_st, b, oy, ox, c, PH, PW, (float)v - mean);
     if (resized_u8) resized_u8[((size_t)b * OH + oy) * OW * 3 + o] = (uint8_t)v;
 }
 
 // f32 CHW (the reference's model input, track_predictor.py:49) -> normalised padded NHWC4.
-__global__ __launch_bounds__(256) void chw_to_nhwc4_norm(const float* __restrict__ img, float* __restrict__ out, int OH,
+__global__ __launch_bounds__(256) void chw_to_nhwc4_norm(const float* __restrict__ img, void* __restrict__ out, int out_st, int OH,
                                                          int OW, int PH, int PW, float m0, float m1, float m2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (i >= OH * OW) return;
     const int oy = i / OW, ox = i - oy * OW;
     const float* p = img + (size_t)b * 3 * OH * OW;
-    f32x4 v = {p[i] - m0, p[(size_t)OH * OW + i] - m1, p[(size_t)2 * OH * OW + i] - m2, 0.f};
-    *reinterpret_cast<f32x4*>(out + (((size_t)b * PH + oy) * PW + ox) * 4) = v;
+    if (out_st == 0) {
+        f32x4 v = {p[i] - m0, p[(size_t)OH * OW + i] - m1, p[(size_t)2 * OH * OW + i] - m2, 0.f};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (((size_t)b * PH + oy) * PW + ox) * 4) = v;
+    } else {
+        input_store(out, out_st, b, oy, ox, 0, PH, PW, p[i] - m0);
+        input_store(out, out_st, b, oy, ox, 1, PH, PW, p[(size_t)OH * OW + i] - m1);
+        input_store(out, out_st, b, oy, ox, 2, PH, PW, p[(size_t)2 * OH * OW + i] - m2);
+    }
 }
 
 // max_pool2d(k=3, s=2, p=1) on NHWC (f32 or 16-bit storage), C % 4 == 0.  One thread per (pixel, 4 channels).
@@ -166,18 +182,18 @@ int apse_k_round16(const float* x, uint16_t* y, size_t n, int dtype, hipStream_t
     hipLaunchKernelGGL(round16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, n, dtype);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
-int apse_k_pil_resize(const uint8_t* src, uint8_t* tmp, float* out, uint8_t* resized_u8, const int* hb, const int* hc,
+int apse_k_pil_resize(const uint8_t* src, uint8_t* tmp, void* out, int out_st, uint8_t* resized_u8, const int* hb, const int* hc,
                       int hk, const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,
                       const float* mean, hipStream_t s) {
     if ((W & 3) != 0 || (size_t)W * 3 > 150000) return APSE_E_INVALID;
     hipLaunchKernelGGL(pil_resize_h, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
                        (size_t)H * W * 3, (size_t)H * OW * 3);
-    hipLaunchKernelGGL(pil_resize_v_norm, dim3((OW * 3 + 255) / 256, OH, B), dim3(256), 0, s, tmp, out, vb, vc, OH, OW, vk,
+    hipLaunchKernelGGL(pil_resize_v_norm, dim3((OW * 3 + 255) / 256, OH, B), dim3(256), 0, s, tmp, out, out_st, vb, vc, OH, OW, vk,
                        PH, PW, mean[0], mean[1], mean[2], (size_t)H * OW * 3, resized_u8);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
-int apse_k_chw_norm(const float* img, float* out, int B, int OH, int OW, int PH, int PW, const float* mean, hipStream_t s) {
-    hipLaunchKernelGGL(chw_to_nhwc4_norm, dim3((OH * OW + 255) / 256, B), dim3(256), 0, s, img, out, OH, OW, PH, PW, mean[0],
+int apse_k_chw_norm(const float* img, void* out, int out_st, int B, int OH, int OW, int PH, int PW, const float* mean, hipStream_t s) {
+    hipLaunchKernelGGL(chw_to_nhwc4_norm, dim3((OH * OW + 255) / 256, B), dim3(256), 0, s, img, out, out_st, OH, OW, PH, PW, mean[0],
                        mean[1], mean[2]);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }

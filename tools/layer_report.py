@@ -58,10 +58,12 @@ items = []
 for r in fr:
     kn = r['Kernel_Name']
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    if 'conv_igemm' in kn.split('(')[0] or 'conv1x1_stream' in kn.split('(')[0]:
+    if any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16')):
         # the __bf16 template argument defeats rocprofv3's demangler: fall back to the raw name
         if 'conv1x1_stream' in kn:
             lab = 'stream' + (kn.split('<')[1].split('>')[0] if '<' in kn else '')
+        elif 'conv_glds16' in kn:
+            lab = 'glds' + (kn.split('<')[1].split('>')[0] if '<' in kn else '')
         else:
             lab = kn.split('<')[1].split('>')[0] if '<' in kn else kn.split('conv_igemm')[1][:28]
         items.append([lab[-22:], d, r['Grid_Size_X'], r['Grid_Size_Y']])
@@ -82,7 +84,7 @@ for k, (d, fl, n) in agg.items():
 others = collections.Counter()
 for r in fr:
     kn = r['Kernel_Name']
-    if not ('conv_igemm' in kn.split('(')[0] or 'conv1x1_stream' in kn.split('(')[0] or 'conv_splitk_reduce' in kn.split('(')[0]):
+    if not any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'conv_splitk_reduce')):
         others[kn.split('(')[0][:40]] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 print('non-conv kernels:')
 for k, v in others.most_common(14):
