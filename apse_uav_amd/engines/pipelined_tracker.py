@@ -6,10 +6,12 @@ detector is stateless; only the association (ids) is sequential.  This driver ke
 each on its own HIP stream and detector context (weights replicated, ~250 MB each), and runs the association on
 the host strictly in frame order from each frame's results block -- the same split a frame-sharded multi-GPU run
 uses, inside one GPU.  Small-grid layers of one frame (res4 / res5 at batch 1 have one tile per CU)
-then overlap with other frames' work: ~175 vs ~155 frames/s at 3840x2160 on one MI355X, at ``depth`` x the
-per-frame latency (measured: depth 2 / 3 / 4 = 176 / 180 / 183 frames/s; depth 6 collapses to 45 -- more streams than
-the device serves concurrently only add queue switching, so keep depth <= 4).  Results are identical to
-``RcnnTracker.next_frame`` frame by frame (tests/test_gpu_detector.py; a 48-frame 4K sequence gives the same CSV).
+then overlap with other frames' work: at 3840x2160 on one MI355X (round 2, tools/pipeline_probe.py) depth 2 / 3 / 4 / 6 / 8 =
+179 / 177 / 195 / 188 / 203 frames/s against ~155 for the plain loop, at ``depth`` x the per-frame latency.  (Round 1 reported
+a collapse to 45 frames/s at depth 6 and fenced the depth at 4: that was the measurement, not the device -- a slot's context
+is built on its first forward (~0.2 s), and with fewer warm-up frames than slots those builds landed inside the timed
+region.  Every slot now gets a priming forward first; hardware-queue count (GPU_MAX_HW_QUEUES 4 vs 8) makes no difference.)
+Results are identical to ``RcnnTracker.next_frame`` frame by frame (tests/test_gpu_detector.py, tests/test_gpu_fullsize.py).
 
     drv = PipelinedRcnnTracker(config, image_size, weights, depth=3, detector_state=sd)
     for frame_idx, objects in drv.run(frames):              # frames: iterable of HxWx3 uint8 BGR arrays
@@ -25,9 +27,12 @@ from .rcnn_tracker import RcnnTracker, instances_from_record
 from .track_predictor import FrameUploader
 
 
+MAX_DEPTH = 8           # ~250 MB of weights + 1.6 GB of activations per slot; beyond ~4 the gain is within the noise
+
+
 class PipelinedRcnnTracker:
     def __init__(self, config, image_size, weights, depth=3, want_masks=False, detector_state=None, **tracker_kwargs):
-        assert 1 <= depth <= 4, "depth 2..4 (more frames in flight than the device runs concurrently is slower, see the module text)"
+        assert 1 <= depth <= MAX_DEPTH, "depth 1..%d" % MAX_DEPTH
         self.tracker = RcnnTracker(config, image_size, weights, detector_state=detector_state, **tracker_kwargs)
         self.depth = depth
         self.want_masks = want_masks

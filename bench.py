@@ -57,7 +57,7 @@ def main():
                     help="frames start in pinned host memory and are uploaded inside the timed region on a copy stream "
                          "(double-buffered, overlapped with compute): the PCIe-inclusive rate noted in DESIGN.md, never "
                          "the headline value")
-    ap.add_argument("--throughput-depth", type=int, default=3,
+    ap.add_argument("--throughput-depth", type=int, default=4,
                     help="after the timed region, also measure a pipelined run with this many frames in flight and "
                          "report it as `throughput_mode` (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -159,7 +159,8 @@ def main():
             m2.load_state_dict(sd)
             m2.attach_association_head(tracker.association_head)
             models.append(m2)
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(depth - 1)]
+    # every slot of a software pipeline gets its own non-default stream
+    streams = [torch.cuda.current_stream()] if depth == 1 else [torch.cuda.Stream() for _ in range(depth)]
 
     pinned = torch.stack([torch.from_numpy(f) for f in host_frames]).pin_memory() if args.from_host else None
     copy_stream = torch.cuda.Stream() if args.from_host else None
@@ -182,6 +183,7 @@ def main():
                 prefetch(i)
             batch, ev = upload.pop(i)
             streams[k].wait_event(ev)
+            batch.record_stream(streams[k])       # allocated on the copy stream, consumed here: keep the allocator off it until then
             prefetch(i + 1)                       # next step's upload overlaps this step's compute
         else:
             batch = frames[idx] if B > 1 else frames[idx[0]:idx[0] + 1]
@@ -205,6 +207,13 @@ def main():
         submit(i)
         return collect(i, timed)
 
+    # a context is built on its first forward (~0.2 s: weight packing + upload): prime every pipeline slot before the W warm-up
+    # steps, or slots beyond W are created INSIDE the timed region (round 1's "depth 6 collapses to 45 frames/s")
+    for k in range(1, depth):
+        with torch.cuda.stream(streams[k]):
+            models[k].preprocess_frames(frames[0:B])
+            models[k].run(B)
+            models[k].read(B)
     for i in range(args.warmup):
         res = step(i, False)
     torch.cuda.synchronize()
@@ -222,21 +231,28 @@ def main():
         N_sum += res.total
 
     inflight = []          # (step index, submit time)
+    trace = [] if os.environ.get("APSE_BENCH_TRACE") else None      # (submit ms, collect ms) per step -> stderr
     for i in range(args.steps):
         if not args.no_events:
             on = i % max(args.event_every, 1) == 0
             n_instr += int(on)
             lib.apse_profile(models[i % depth]._ctx, 1 if on else 0)
         inflight.append((args.warmup + i, time.perf_counter()))
+        t_a = time.perf_counter()
         submit(args.warmup + i)
+        t_b = time.perf_counter()
         if len(inflight) == depth:
             j, ts = inflight.pop(0)
             account(collect(j, True))
             lat.append(time.perf_counter() - ts)
+        if trace is not None:
+            trace.append((round(1e3 * (t_b - t_a), 2), round(1e3 * (time.perf_counter() - t_b), 2)))
     while inflight:
         j, ts = inflight.pop(0)
         account(collect(j, True))
         lat.append(time.perf_counter() - ts)
+    if trace is not None:
+        print("submit/collect ms per step:", trace, file=sys.stderr)
     if dist is not None:
         packed = gather_records(records, rank, world, coll_dev, unpack=False)   # the single exchange step (RCCL over xGMI)
         if rank == 0:
@@ -360,6 +376,7 @@ def rehearse_spawn(args, rank, world, backend):
 
 
 def throughput_mode(cfg, sd, tracker, model, frames, nres, B, depth, replay, steps=24, warmup=4):
+    warmup = max(warmup, depth + 1)          # every slot's context is built (first forward) before the timed part
     """Same frames, same per-frame results, `depth` frames in flight on separate streams / contexts
     (apse_uav_amd.engines.pipelined_tracker.PipelinedRcnnTracker: detector per frame on its own stream, association
     on the host in frame order): the small-grid layers of one frame (res4/res5 at batch 1 fill ~1 block per CU)
