@@ -66,6 +66,7 @@ def load():
         "apse_set_weight": ([vp, C.c_char_p, vp, C.POINTER(C.c_int64), i], i),
         "apse_finalize_weights": ([vp], i),
         "apse_set_resize_tables": ([vp, vp, vp, i, vp, vp, i], i),
+        "apse_set_camera": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i, vp, i, i], i),
         "apse_preprocess_frames": ([vp, vp, i, vp], i),
         "apse_preprocess_images": ([vp, vp, i, vp], i),
         "apse_backbone": ([vp, i, vp], i),
@@ -115,7 +116,7 @@ def load():
 
 
 EXPORTS = ["apse_create", "apse_destroy", "apse_last_error", "apse_version", "apse_set_weight", "apse_finalize_weights",
-           "apse_set_resize_tables", "apse_preprocess_frames", "apse_preprocess_images", "apse_backbone", "apse_rpn", "apse_rpn_levels",
+           "apse_set_resize_tables", "apse_set_camera", "apse_preprocess_frames", "apse_preprocess_images", "apse_backbone", "apse_rpn", "apse_rpn_levels",
            "apse_box_head", "apse_set_detections", "apse_mask_tail", "apse_embed", "apse_forward", "apse_results_describe",
            "apse_read_results", "apse_copy_mask_window", "apse_feature_shape", "apse_export_feature", "apse_debug_tensor",
            "apse_flops", "apse_profile", "apse_profile_read", "apse_conv_packed_elems", "apse_conv_pack_weight", "apse_conv2d", "apse_maxpool3x3s2",

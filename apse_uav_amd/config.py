@@ -111,7 +111,7 @@ def get_cfg():
         "TEST": {"DETECTIONS_PER_IMAGE": 100},
         "DATASETS": {"TRAIN": ("coco_2017_train",), "TEST": ("coco_2017_val",)},
         # build-specific knobs (not in the reference): storage dtype and batch of the HIP path
-        "APSE": {"DTYPE": "f32", "MAX_BATCH": 1, "FUSED_PREPROC": False, "STORAGE16": True},
+        "APSE": {"DTYPE": "f32", "MAX_BATCH": 1, "FUSED_PREPROC": True, "STORAGE16": True},
     })
 
 

@@ -4,6 +4,7 @@
 // except apse_read_results).
 #include "apse_common.h"
 #include "../../include/apse_hip.h"
+#include "preproc_pixel.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -24,7 +25,7 @@ struct PasteParams {
 };
 extern "C" {
 int apse_k_pil_resize(const uint8_t*, uint8_t*, void*, int, uint8_t*, const int*, const int*, int, const int*, const int*, int, int,
-                      int, int, int, int, int, int, const float*, hipStream_t);
+                      int, int, int, int, int, int, const float*, const UndistortParams*, const uint8_t*, hipStream_t);
 int apse_k_chw_norm(const float*, void*, int, int, int, int, int, int, const float*, hipStream_t);
 int apse_k_maxpool3x3s2(const void*, void*, int, int, int, int, int, hipStream_t);
 int apse_k_subsample2(const void*, void*, int, int, int, int, int, hipStream_t);
@@ -52,7 +53,6 @@ int apse_k_mask_paste(const PasteParams*, int, int*, int*, hipStream_t);
 int apse_k_closest_points(const uint64_t*, const int*, const int*, const int*, const int*, const int*, const int*, int, int,
                           int, int, int, int*, unsigned long long*, hipStream_t);
 int apse_k_closest_single(const uint64_t*, int, int, int, float, float, unsigned long long*, hipStream_t);
-struct UndistortParams { double ir[9]; double k[12]; double fx, fy, u0, v0; int H, W; int do_undistort, do_gamma; };
 int apse_k_undistort_gamma(const UndistortParams*, const uint8_t*, uint8_t*, const uint8_t*, int, hipStream_t);
 int apse_k_bits_to_dense(const uint64_t*, const int*, int, int, int, uint8_t*, hipStream_t);
 int apse_k_dense_to_bits(const uint8_t*, int, int, int, uint64_t*, unsigned long long*, hipStream_t);
@@ -107,6 +107,7 @@ struct apse_ctx {
     float* emb_raw = nullptr;
     float* rf_mask = nullptr; size_t rf_mask_floats = 0;      // apse_roi_features: masks at p2 resolution (grown on demand)
     bool box_maxc_clean = false;
+    UndistortParams cam; bool cam_on = false; uint8_t* cam_lut = nullptr;     // apse_set_camera: fused undistort + gamma in apse_preprocess_frames
     int hint_total = 8;      // detections seen in the previous forward: sizes the GRID of the packed-list GEMMs, nothing else
     // per-kernel profiling with HIP events on the caller's stream (bench.py roofline)
     bool prof_on = false; std::vector<hipEvent_t> ev_pool; int ev_used = 0;
@@ -788,7 +789,8 @@ int apse_preprocess_frames(apse_ctx* c, const uint8_t* frames, int batch, void* 
     if (!c->hb) return fail(c, APSE_E_STATE, "resize tables not set");
     const apse_config& g = c->cfg;
     int rc = apse_k_pil_resize(frames, c->rs_tmp, c->t["input"].p, c->t["input"].st, nullptr, c->hb, c->hc, c->hk, c->vb, c->vc, c->vk, batch,
-                               g.frame_h, g.frame_w, g.image_h, g.image_w, c->PH, c->PW, g.pixel_mean, (hipStream_t)stream);
+                               g.frame_h, g.frame_w, g.image_h, g.image_w, c->PH, c->PW, g.pixel_mean, c->cam_on ? &c->cam : nullptr, c->cam_lut,
+                               (hipStream_t)stream);
     return rc ? fail(c, rc, "pil resize launch failed") : APSE_OK;
 }
 
@@ -1301,11 +1303,9 @@ int apse_l2_normalize(const float* x, float* y, int n, int D, void* stream) {
 int apse_sqdist(const float* a, const float* b, int O, int N, int D, float* out, void* stream) {
     return apse_k_sqdist(a, b, O, N, D, out, (hipStream_t)stream);
 }
-int apse_undistort_gamma(const uint8_t* src, uint8_t* dst, int B, int H, int W, const double* m, const double* dist, int ndist,
-                         const uint8_t* lut, int do_undistort, int do_gamma, void* stream) {
-    if (!src || !dst || !m || ndist > 14 || (do_gamma && !lut)) return APSE_E_INVALID;
-    UndistortParams p;
+static int fill_camera(UndistortParams& p, int H, int W, const double* m, const double* dist, int ndist, int do_undistort, int do_gamma) {
     memset(&p, 0, sizeof p);
+    if (!m || ndist > 14 || ndist < 0 || (ndist > 0 && !dist)) return APSE_E_INVALID;
     for (int i = 0; i < ndist && i < 12; ++i) p.k[i] = dist[i];
     if (ndist > 12 && (dist[12] != 0.0 || (ndist > 13 && dist[13] != 0.0))) return APSE_E_INVALID;   // tilt model not built
     // inverse of the 3x3 camera matrix (double, adjugate / determinant)
@@ -1318,12 +1318,39 @@ int apse_undistort_gamma(const uint8_t* src, uint8_t* dst, int B, int H, int W, 
     p.ir[6] = (dd * h - e * g) * id; p.ir[7] = (b * g - a * h) * id; p.ir[8] = (a * e - b * dd) * id;
     p.fx = m[0]; p.fy = m[4]; p.u0 = m[2]; p.v0 = m[5];
     p.H = H; p.W = W; p.do_undistort = do_undistort; p.do_gamma = do_gamma;
+    return APSE_OK;
+}
+
+int apse_undistort_gamma(const uint8_t* src, uint8_t* dst, int B, int H, int W, const double* m, const double* dist, int ndist,
+                         const uint8_t* lut, int do_undistort, int do_gamma, void* stream) {
+    if (!src || !dst || (do_gamma && !lut)) return APSE_E_INVALID;
+    UndistortParams p;
+    int rc = fill_camera(p, H, W, m, dist, ndist, do_undistort, do_gamma);
+    if (rc) return rc;
     return apse_k_undistort_gamma(&p, src, dst, lut, B, (hipStream_t)stream);
+}
+
+int apse_set_camera(apse_ctx* c, const double* m, const double* dist, int ndist, const uint8_t* lut_host, int do_undistort, int do_gamma) {
+    if (!c) return APSE_E_INVALID;
+    if (!do_undistort && !do_gamma) { c->cam_on = false; return APSE_OK; }
+    if (do_gamma && !lut_host) return fail(c, APSE_E_INVALID, "gamma needs a 256-entry LUT");
+    UndistortParams p;
+    int rc = fill_camera(p, c->cfg.frame_h, c->cfg.frame_w, m, dist, ndist, do_undistort, do_gamma);
+    if (rc) return fail(c, rc, "bad camera parameters (3x3 matrix, <= 14 distortion coefficients, tilt terms zero)");
+    hipSetDevice(c->cfg.device);
+    if (!c->cam_lut) {
+        c->cam_lut = dalloc<uint8_t>(c, 256);
+        if (!c->cam_lut) return fail(c, APSE_E_NOMEM, "camera LUT alloc");
+    }
+    if (lut_host) HIPCHK(c, hipMemcpy(c->cam_lut, lut_host, 256, hipMemcpyHostToDevice));
+    c->cam = p;
+    c->cam_on = true;
+    return APSE_OK;
 }
 int apse_resize_normalize(const uint8_t* frames, uint8_t* tmp, float* out, uint8_t* resized, const int* hb, const int* hc, int hk,
                           const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,
                           const float* mean3, void* stream) {
-    return apse_k_pil_resize(frames, tmp, out, 0, resized, hb, hc, hk, vb, vc, vk, B, H, W, OH, OW, PH, PW, mean3, (hipStream_t)stream);
+    return apse_k_pil_resize(frames, tmp, out, 0, resized, hb, hc, hk, vb, vc, vk, B, H, W, OH, OW, PH, PW, mean3, nullptr, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -6,6 +6,8 @@
 //  * stem max-pool 3x3/2 and FPN p6 subsample (detectron2 ResNet stem / LastLevelMaxPool,
 //    reached from track_rcnn.py:42).
 #include "apse_common.h"
+#include "preproc_pixel.h"
+#include <string.h>
 
 #define PIL_PRECISION_BITS 22
 
@@ -17,15 +19,27 @@ __device__ __forceinline__ int clip8(int v) {
 // Horizontal pass: one block per input row.  The row (W*3 bytes, BGR interleaved) is staged in
 // LDS with coalesced 4-byte loads; each thread then produces output samples (ox, c).
 // bounds: [OW][2] = (xmin, count); coef: [OW][ksize] int32 (Pillow normalize_coeffs_8bpc).
+// FUSED: the row is not copied but COMPUTED while staging -- undistort gather + Lab gamma of the raw frame (preproc_pixel.h,
+// the reference's preprocess_img) -- so a pre-processed 4K frame is never written to / re-read from HBM (2 x 24.9 MB per frame
+// and one launch less than undistort_gamma -> pil_resize_h).  Same per-pixel function, same bytes as the two-kernel form.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp,
                                                     const int* __restrict__ bounds, const int* __restrict__ coef,
                                                     int H, int W, int OW, int ksize, size_t src_img_stride,
-                                                    size_t tmp_img_stride) {
+                                                    size_t tmp_img_stride, const UndistortParams cam, const uint8_t* __restrict__ lut) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint8_t* row = reinterpret_cast<uint8_t*>(smem);
     const int y = blockIdx.x, b = blockIdx.y;
     const uint8_t* srow = src + (size_t)b * src_img_stride + (size_t)y * W * 3;
     const int nbytes = W * 3;
+    if constexpr (FUSED) {
+        const uint8_t* frame = src + (size_t)b * src_img_stride;
+        for (int x = threadIdx.x; x < W; x += blockDim.x) {
+            int c0, c1, c2;
+            undistort_gamma_pixel(cam, frame, lut, x, y, c0, c1, c2);
+            row[x * 3 + 0] = (uint8_t)c0; row[x * 3 + 1] = (uint8_t)c1; row[x * 3 + 2] = (uint8_t)c2;
+        }
+    } else
     // W*3 is a multiple of 4 for every supported width (W % 4 == 0); rows start 4-byte aligned.
     if ((nbytes & 15) == 0) {              // 16-byte rows (W % 16 == 0, e.g. 3840): three 16-byte loads per thread, all in flight
         const uint4* s16 = reinterpret_cast<const uint4*>(srow);
@@ -184,10 +198,18 @@ int apse_k_round16(const float* x, uint16_t* y, size_t n, int dtype, hipStream_t
 }
 int apse_k_pil_resize(const uint8_t* src, uint8_t* tmp, void* out, int out_st, uint8_t* resized_u8, const int* hb, const int* hc,
                       int hk, const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,
-                      const float* mean, hipStream_t s) {
+                      const float* mean, const UndistortParams* cam, const uint8_t* lut, hipStream_t s) {
     if ((W & 3) != 0 || (size_t)W * 3 > 150000) return APSE_E_INVALID;
-    hipLaunchKernelGGL(pil_resize_h, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
-                       (size_t)H * W * 3, (size_t)H * OW * 3);
+    UndistortParams none;
+    memset(&none, 0, sizeof none);
+    if (cam && (cam->do_undistort || cam->do_gamma)) {
+        if (cam->H != H || cam->W != W) return APSE_E_INVALID;
+        hipLaunchKernelGGL(pil_resize_h<true>, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
+                           (size_t)H * W * 3, (size_t)H * OW * 3, *cam, lut);
+    } else {
+        hipLaunchKernelGGL(pil_resize_h<false>, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
+                           (size_t)H * W * 3, (size_t)H * OW * 3, none, nullptr);
+    }
     hipLaunchKernelGGL(pil_resize_v_norm, dim3((OW * 3 + 255) / 256, OH, B), dim3(256), 0, s, tmp, out, out_st, vb, vc, OH, OW, vk,
                        PH, PW, mean[0], mean[1], mean[2], (size_t)H * OW * 3, resized_u8);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;

@@ -44,11 +44,18 @@ class PipelinedRcnnTracker:
             m.to(self.device)
             m.load_state_dict(first._state)
             m.attach_association_head(self.tracker.association_head)
+            m.set_camera(first._camera)
             self.models.append(m)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
         self._uploader = FrameUploader(self.device, self.tracker.predictor.input_format, nslots=depth + 1)
         self._inflight = collections.deque()
         self._submitted = 0
+
+    def set_camera(self, cam_params, gamma=2.0, fused=None):
+        """TrackPredictor.set_camera for every slot (undistort + gamma in front of the resize)."""
+        self.tracker.predictor.set_camera(cam_params, gamma, fused)
+        for m in self.models[1:]:
+            m.set_camera(self.models[0]._camera)
 
     # ------------------------------------------------------------------ one frame in, zero or one out
     def submit(self, frame):

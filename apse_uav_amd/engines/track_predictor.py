@@ -119,10 +119,20 @@ class TrackPredictor:
         self._prefetched = None
         self._last_slot = None
 
-    def set_camera(self, cam_params, gamma=2.0):
-        """Enables undistort + Lab-gamma in front of the resize (preprocess_img, visualize_uav.py:56-71)."""
+    def set_camera(self, cam_params, gamma=2.0, fused=None):
+        """Enables undistort + Lab-gamma in front of the resize (preprocess_img, visualize_uav.py:56-71).  ``fused`` (default
+        cfg.APSE.FUSED_PREPROC): computed inside the resize kernel's row staging (no intermediate 4K frame in HBM); otherwise as
+        a separate kernel on the uploaded frame.  Both give the same bytes (tests/test_gpu_detector.py)."""
         from ..utils.preprocess import FramePreprocessor
-        self.frame_preprocessor = FramePreprocessor(cam_params, gamma)
+        pp = FramePreprocessor(cam_params, gamma)
+        if fused is None:
+            fused = bool(self.cfg.APSE.get("FUSED_PREPROC", True))
+        if fused:
+            self.frame_preprocessor = None
+            self.model.set_camera(pp)
+        else:
+            self.model.set_camera(None)
+            self.frame_preprocessor = pp
 
     # ------------------------------------------------------------------ ingest
     def _up(self):

@@ -101,6 +101,7 @@ class TrackRCNN:
         self._ctx_key = None
         self._lay = None
         self._host = None
+        self._camera = None                   # FramePreprocessor: undistort + gamma fused into preprocess_frames
         self.last_results = None
 
     # ---- nn.Module-like surface the reference touches
@@ -120,6 +121,23 @@ class TrackRCNN:
         """Fuses the tracker's AssociationHead (rcnn_tracker.py:55-57) into the per-frame launch sequence."""
         self._assoc = head
         self._drop_ctx()
+
+    def set_camera(self, preproc):
+        """``preproc``: utils.preprocess.FramePreprocessor (camera matrix, distortion, gamma LUT) or None.  The context then runs
+        undistort + gamma inside ``apse_preprocess_frames`` (include/apse_hip.h: apse_set_camera)."""
+        self._camera = preproc
+        if self._ctx is not None:
+            self._push_camera()
+
+    def _push_camera(self):
+        lib = _lib.load()
+        pc = self._camera
+        if pc is None:
+            _lib.check(lib.apse_set_camera(self._ctx, None, None, 0, None, 0, 0), self._ctx, "apse_set_camera")
+            return
+        _lib.check(lib.apse_set_camera(self._ctx, pc.mtx.ctypes.data_as(C.POINTER(C.c_double)), pc.dist.ctypes.data_as(C.POINTER(C.c_double)),
+                                       int(pc.dist.size), _lib.ptr(pc.lut_host), int(pc.undistort), int(pc.gamma_correct)),
+                   self._ctx, "apse_set_camera")
 
     def _drop_ctx(self):
         if self._ctx is not None:
@@ -199,6 +217,8 @@ class TrackRCNN:
             lib.apse_destroy(ctx)
             raise
         self._ctx, self._ctx_key, self._lay = ctx, key, lay
+        if self._camera is not None:
+            self._push_camera()
         self._host = torch.empty(lay.bytes, dtype=torch.uint8).pin_memory()
         self._cfg_c = c
 

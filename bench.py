@@ -68,6 +68,9 @@ def main():
                     help="f32 = exact-f32 MFMA (reference numerics, BASELINE configs[1]); bf16 = bf16 matrix cores with "
                          "f32 accumulate/storage for the bulk GEMMs (configs[2]/[4] style)")
     ap.add_argument("--bg-bias", type=float, default=None)
+    ap.add_argument("--preproc", action="store_true",
+                    help="undistort (data/cam_params.json model, fixture copy in tests/golden/) + Lab gamma fused into the resize "
+                         "(BASELINE configs[2] style: --dtype bf16 --batch 4 --preproc)")
     ap.add_argument("--no-entrypoint", action="store_true", help="skip the RcnnTracker.next_frame(np.ndarray) measurement")
     ap.add_argument("--entry-steps", type=int, default=24)
     ap.add_argument("--rehearse-spawn", action="store_true",
@@ -137,6 +140,12 @@ def main():
     cfg.APSE.DTYPE = args.dtype
     tracker = RcnnTracker(cfg, (H, W), asd, detector_state=sd)
     model = tracker.predictor.model
+    if args.preproc:
+        with open(os.path.join(ROOT, "tests", "golden", "cam_params.json")) as fh:
+            cam = json.load(fh)
+        sc = W / 3840.0
+        cam["mtx"] = [[v * sc for v in cam["mtx"][0]], [v * sc for v in cam["mtx"][1]], cam["mtx"][2]]
+        tracker.predictor.set_camera(cam)
 
     # frames of this rank's shard, resident in HBM before timing (8 distinct frames, cycled)
     seq = SyntheticSequence("static", H, W)
@@ -158,6 +167,7 @@ def main():
             m2 = TrackRCNN(cfg)
             m2.load_state_dict(sd)
             m2.attach_association_head(tracker.association_head)
+            m2.set_camera(model._camera)
             models.append(m2)
     # every slot of a software pipeline gets its own non-default stream
     streams = [torch.cuda.current_stream()] if depth == 1 else [torch.cuda.Stream() for _ in range(depth)]
@@ -308,7 +318,7 @@ def main():
             "p50_ms_per_frame": round(1000.0 * float(np.median(lat)) / B, 3),
             "config": {"workload": "static synthetic 3840x2160 sequence, batch=%d %s, Mask R-CNN R-%s-FPN, %d GPU(s), "
                                    "frames sharded per rank" % (B, args.dtype, "101" if blocks == (3, 4, 23, 3) else str(blocks), world),
-                       "frame": "%dx%d" % (W, H), "batch_per_gpu": B, "frames_in_flight": depth, "proposals_per_frame": P_sum / max(args.steps * B, 1),
+                       "frame": "%dx%d" % (W, H), "preproc": "undistort + gamma fused into the resize" if args.preproc else "none", "batch_per_gpu": B, "frames_in_flight": depth, "proposals_per_frame": P_sum / max(args.steps * B, 1),
                        "detections_per_frame": N_sum / max(args.steps * B, 1),
                        "gflop_per_frame_algorithmic": round(flops_frame / 1e9, 2)},
             "roofline": {"bound": "mfma", "kernel": CFG_NAMES[dom], "achieved": round(achieved, 3),

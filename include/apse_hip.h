@@ -98,6 +98,14 @@ int apse_finalize_weights(apse_ctx* ctx);
 int apse_set_resize_tables(apse_ctx* ctx, const int* hbounds, const int* hcoef, int hksize, const int* vbounds,
                            const int* vcoef, int vksize);
 
+/* Optional: preprocess_img of dcnn/scripts/tests/visualize_uav.py:56-71 (cv2.undistort with data/cam_params.json + gamma on the
+ * Lab L channel) fused into apse_preprocess_frames -- the raw frame is undistorted / gamma-corrected while the horizontal
+ * resize pass stages its rows, so no pre-processed 4K frame is ever written to HBM.  m: 3x3 camera matrix (row-major, host
+ * f64), dist: up to 14 coefficients (k1 k2 p1 p2 k3 k4 k5 k6 s1..s4, tilt terms must be 0), lut: 256-entry L table (host).
+ * do_undistort = do_gamma = 0 switches it off.  Synchronous (small host -> device copy). */
+int apse_set_camera(apse_ctx* ctx, const double* m9, const double* dist, int ndist, const uint8_t* lut256_host, int do_undistort,
+                    int do_gamma);
+
 /* ---- per-frame stages (all enqueue on `stream`) ---- */
 /* ResizeShortestEdge.apply_image (PIL bilinear) + preprocess_image: u8 BGR frames [B][frame_h][frame_w][3]
  * -> internal normalised, /32-padded network input (track_predictor.py:48-49, track_rcnn.py:35). */

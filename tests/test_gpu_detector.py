@@ -355,3 +355,34 @@ def test_results_independent_of_history(setup, logdir):
     _log(logdir, "history", dict(n=[o[0] for o in outs], nbytes=[len(o[1]) for o in outs]))
     assert outs[0][0] > 0
     assert outs[0][1] == outs[1][1] == outs[2][1]
+
+
+def test_fused_preproc_equals_two_kernel_form(setup, golden_dir):
+    """undistort + gamma fused into the horizontal resize staging (apse_set_camera) must build the same network input, byte for
+    byte, as the stand-alone apse_undistort_gamma kernel followed by the plain resize -- at the test size and at 3840x2160."""
+    from apse_uav_amd.engines.track_predictor import TrackPredictor
+    from apse_uav_amd.synthetic import SyntheticSequence
+    with open(os.path.join(golden_dir, "cam_params.json")) as f:
+        cam = json.load(f)
+    for (hw, cfg) in ((FRAME, _cfg()), ((2160, 3840), None)):
+        if cfg is None:
+            from apse_uav_amd.config import setup_cfg
+            cfg = setup_cfg()
+        s = hw[1] / 3840.0
+        mtx = np.asarray(cam["mtx"], np.float64)
+        mtx[0] *= s
+        mtx[1] *= s
+        cam_s = dict(mtx=mtx.tolist(), dist=cam["dist"])
+        frame = SyntheticSequence("dynamic", *hw).frame(3)
+        got = []
+        for fused in (True, False):
+            pr = TrackPredictor(cfg, state_dict=setup["sd"])
+            pr.set_camera(cam_s, fused=fused)
+            assert (pr.frame_preprocessor is None) == fused
+            dev = pr._upload([frame])
+            pr.model.preprocess_frames(dev)
+            got.append(pr.model.debug_tensor("input").cpu())
+        plain = TrackPredictor(cfg, state_dict=setup["sd"])
+        plain.model.preprocess_frames(plain._upload([frame]))
+        assert torch.equal(got[0], got[1])
+        assert not torch.equal(got[0], plain.model.debug_tensor("input").cpu())      # the camera model does change the pixels
