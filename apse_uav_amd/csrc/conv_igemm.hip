@@ -675,7 +675,8 @@ static int fast16_shape(const ConvParams& p, int cfg) {
     int c16 = (cfg == 4 || cfg == 5 || cfg == 2) ? 1 : (cfg == 7 ? 6 : cfg);
     // deep-K layers with at least one 256x128 tile per CU: the wider tile halves the filter traffic per FLOP
     // (out2 / rpn_t2 / res4 3x3 at batch 8: +5..7 %)
-    if (c16 == 0 && p.steps_total >= 32 && ((p.M + 255) / 256) * ((p.Cout + 127) / 128) >= 250) c16 = 8;
+    // (K >= 512 since the LDS-DMA kernel took over this tile: lateral 3 / res3 conv1 / res4 shortcut +3..9 %; K >= 1024 before)
+    if (c16 == 0 && p.steps_total >= 16 && ((p.M + 255) / 256) * ((p.Cout + 127) / 128) >= 250) c16 = 8;
     return c16;
 }
 

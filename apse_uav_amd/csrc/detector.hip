@@ -343,11 +343,13 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     p.stream_k = 0;
     if (count_kind == 2) {
         // GEMMs over the packed detection list: the tile shape and the K split fix the f32 summation order, so they are
-        // chosen HERE, once, from plan constants only (a typical list of APSE_EXPECTED_DETS detections; never from
-        // max_batch, the batch of a forward or an earlier frame's count).  A frame's masks / embeddings are then the
-        // same bits whatever ran before it, in whatever batch or shard.  The live count only sizes the grid (m_hint).
+        // chosen HERE, once, from plan constants only (a typical list of APSE_EXPECTED_DETS detections per image of the
+        // context's max_batch -- like every other layer's shape; never from the batch of a forward or an earlier frame's
+        // count).  Within a context a frame's masks / embeddings are then the same bits whatever ran before it, in whatever
+        // batch; contexts with equal configuration (shards, pipeline slots) agree with each other.  The live count only
+        // sizes the grid (m_hint).
         const int kd = c->cfg.dets_per_image < APSE_EXPECTED_DETS ? c->cfg.dets_per_image : APSE_EXPECTED_DETS;
-        const int rows = kd * p.OH * p.OW;
+        const int rows = kd * c->cfg.max_batch * p.OH * p.OW;
         sk = 1;
         cs.cfg = apse_conv_pick_cfg(rows < Mfull ? rows : Mfull, Cout, p.steps_total, &sk);
     }

@@ -8,7 +8,7 @@ path = sys.argv[1]
 ndet = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('pil_resize_h')]
+idx = [i for i, r in enumerate(rows) if 'pil_resize_h' in r['Kernel_Name'].split('(')[0]]
 fr = rows[idx[-2]:idx[-1]]
 t0 = int(fr[0]['Start_Timestamp'])
 span = (int(fr[-1]['End_Timestamp']) - t0) / 1e3
@@ -85,7 +85,7 @@ others = collections.Counter()
 for r in fr:
     kn = r['Kernel_Name']
     if not any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'conv_splitk_reduce')):
-        others[kn.split('(')[0][:40]] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        others[kn.split('(')[0].replace('void ', '')[:40]] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 print('non-conv kernels:')
 for k, v in others.most_common(14):
     print('  %-42s %8.1f us' % (k, v))
