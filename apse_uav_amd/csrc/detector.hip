@@ -25,7 +25,8 @@ struct PasteParams {
 };
 extern "C" {
 int apse_k_pil_resize(const uint8_t*, uint8_t*, void*, int, uint8_t*, const int*, const int*, int, const int*, const int*, int, int,
-                      int, int, int, int, int, int, const float*, const UndistortParams*, const uint8_t*, hipStream_t);
+                      int, int, int, int, int, int, const float*, const UndistortParams*, const uint8_t*, const void*, const float*, hipStream_t);
+int apse_k_undistort_build_map(const UndistortParams*, void*, float*, hipStream_t);
 int apse_k_chw_norm(const float*, void*, int, int, int, int, int, int, const float*, hipStream_t);
 int apse_k_maxpool3x3s2(const void*, void*, int, int, int, int, int, hipStream_t);
 int apse_k_subsample2(const void*, void*, int, int, int, int, int, hipStream_t);
@@ -107,7 +108,7 @@ struct apse_ctx {
     float* emb_raw = nullptr;
     float* rf_mask = nullptr; size_t rf_mask_floats = 0;      // apse_roi_features: masks at p2 resolution (grown on demand)
     bool box_maxc_clean = false;
-    UndistortParams cam; bool cam_on = false; uint8_t* cam_lut = nullptr;     // apse_set_camera: fused undistort + gamma in apse_preprocess_frames
+    UndistortParams cam; bool cam_on = false; uint8_t* cam_lut = nullptr; void* cam_map = nullptr; float* cam_lin = nullptr;     // apse_set_camera: fused undistort + gamma in apse_preprocess_frames
     int hint_total = 8;      // detections seen in the previous forward: sizes the GRID of the packed-list GEMMs, nothing else
     // per-kernel profiling with HIP events on the caller's stream (bench.py roofline)
     bool prof_on = false; std::vector<hipEvent_t> ev_pool; int ev_used = 0;
@@ -791,7 +792,7 @@ int apse_preprocess_frames(apse_ctx* c, const uint8_t* frames, int batch, void* 
     if (!c->hb) return fail(c, APSE_E_STATE, "resize tables not set");
     const apse_config& g = c->cfg;
     int rc = apse_k_pil_resize(frames, c->rs_tmp, c->t["input"].p, c->t["input"].st, nullptr, c->hb, c->hc, c->hk, c->vb, c->vc, c->vk, batch,
-                               g.frame_h, g.frame_w, g.image_h, g.image_w, c->PH, c->PW, g.pixel_mean, c->cam_on ? &c->cam : nullptr, c->cam_lut,
+                               g.frame_h, g.frame_w, g.image_h, g.image_w, c->PH, c->PW, g.pixel_mean, c->cam_on ? &c->cam : nullptr, c->cam_lut, c->cam_map, c->cam_lin,
                                (hipStream_t)stream);
     return rc ? fail(c, rc, "pil resize launch failed") : APSE_OK;
 }
@@ -1345,6 +1346,15 @@ int apse_set_camera(apse_ctx* c, const double* m, const double* dist, int ndist,
         if (!c->cam_lut) return fail(c, APSE_E_NOMEM, "camera LUT alloc");
     }
     if (lut_host) HIPCHK(c, hipMemcpy(c->cam_lut, lut_host, 256, hipMemcpyHostToDevice));
+    // the remap table depends on the camera only: built here once (f64 rational model per pixel), read per frame (8 B per pixel)
+    if (!c->cam_map) {
+        c->cam_map = dalloc<uint64_t>(c, (size_t)c->cfg.frame_h * c->cfg.frame_w, false);
+        c->cam_lin = dalloc<float>(c, 256, false);
+        if (!c->cam_map || !c->cam_lin) return fail(c, APSE_E_NOMEM, "camera map alloc");
+    }
+    rc = apse_k_undistort_build_map(&p, c->cam_map, c->cam_lin, nullptr);
+    if (rc) return fail(c, rc, "camera map launch failed");
+    HIPCHK(c, hipDeviceSynchronize());
     c->cam = p;
     c->cam_on = true;
     return APSE_OK;
@@ -1352,7 +1362,7 @@ int apse_set_camera(apse_ctx* c, const double* m, const double* dist, int ndist,
 int apse_resize_normalize(const uint8_t* frames, uint8_t* tmp, float* out, uint8_t* resized, const int* hb, const int* hc, int hk,
                           const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,
                           const float* mean3, void* stream) {
-    return apse_k_pil_resize(frames, tmp, out, 0, resized, hb, hc, hk, vb, vc, vk, B, H, W, OH, OW, PH, PW, mean3, nullptr, nullptr, (hipStream_t)stream);
+    return apse_k_pil_resize(frames, tmp, out, 0, resized, hb, hc, hk, vb, vc, vk, B, H, W, OH, OW, PH, PW, mean3, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -26,7 +26,8 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp,
                                                     const int* __restrict__ bounds, const int* __restrict__ coef,
                                                     int H, int W, int OW, int ksize, size_t src_img_stride,
-                                                    size_t tmp_img_stride, const UndistortParams cam, const uint8_t* __restrict__ lut) {
+                                                    size_t tmp_img_stride, const UndistortParams cam, const uint8_t* __restrict__ lut,
+                                                    const int2* __restrict__ cam_map, const float* __restrict__ cam_lin) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint8_t* row = reinterpret_cast<uint8_t*>(smem);
     const int y = blockIdx.x, b = blockIdx.y;
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ 
         const uint8_t* frame = src + (size_t)b * src_img_stride;
         for (int x = threadIdx.x; x < W; x += blockDim.x) {
             int c0, c1, c2;
-            undistort_gamma_pixel(cam, frame, lut, x, y, c0, c1, c2);
+            undistort_gamma_pixel(cam, frame, lut, x, y, c0, c1, c2, cam_map, cam_lin);
             row[x * 3 + 0] = (uint8_t)c0; row[x * 3 + 1] = (uint8_t)c1; row[x * 3 + 2] = (uint8_t)c2;
         }
     } else
@@ -198,17 +199,18 @@ int apse_k_round16(const float* x, uint16_t* y, size_t n, int dtype, hipStream_t
 }
 int apse_k_pil_resize(const uint8_t* src, uint8_t* tmp, void* out, int out_st, uint8_t* resized_u8, const int* hb, const int* hc,
                       int hk, const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,
-                      const float* mean, const UndistortParams* cam, const uint8_t* lut, hipStream_t s) {
+                      const float* mean, const UndistortParams* cam, const uint8_t* lut, const void* cam_map, const float* cam_lin,
+                      hipStream_t s) {
     if ((W & 3) != 0 || (size_t)W * 3 > 150000) return APSE_E_INVALID;
     UndistortParams none;
     memset(&none, 0, sizeof none);
     if (cam && (cam->do_undistort || cam->do_gamma)) {
         if (cam->H != H || cam->W != W) return APSE_E_INVALID;
         hipLaunchKernelGGL(pil_resize_h<true>, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
-                           (size_t)H * W * 3, (size_t)H * OW * 3, *cam, lut);
+                           (size_t)H * W * 3, (size_t)H * OW * 3, *cam, lut, reinterpret_cast<const int2*>(cam_map), cam_lin);
     } else {
         hipLaunchKernelGGL(pil_resize_h<false>, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
-                           (size_t)H * W * 3, (size_t)H * OW * 3, none, nullptr);
+                           (size_t)H * W * 3, (size_t)H * OW * 3, none, nullptr, nullptr, nullptr);
     }
     hipLaunchKernelGGL(pil_resize_v_norm, dim3((OW * 3 + 255) / 256, OH, B), dim3(256), 0, s, tmp, out, out_st, vb, vc, OH, OW, vk,
                        PH, PW, mean[0], mean[1], mean[2], (size_t)H * OW * 3, resized_u8);

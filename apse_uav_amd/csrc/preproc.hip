@@ -20,6 +20,21 @@ __global__ __launch_bounds__(256) void undistort_gamma(const UndistortParams p, 
     o[0] = (uint8_t)c0; o[1] = (uint8_t)c1; o[2] = (uint8_t)c2;
 }
 
+// Built once per camera (apse_set_camera): the remap table of undistort_map_pixel and srgb_to_lin of the 256 byte values.
+__global__ __launch_bounds__(256) void undistort_build_map(const UndistortParams p, int2* __restrict__ map, float* __restrict__ lin) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (y == 0 && blockIdx.x == 0) lin[threadIdx.x] = pp_srgb_to_lin((float)threadIdx.x / 255.f);
+    if (x >= p.W) return;
+    int sx, sy, fx, fy;
+    undistort_map_pixel(p, x, y, sx, sy, fx, fy);
+    map[(size_t)y * p.W + x] = int2{sx, (sy << 10) | (fx << 5) | fy};
+}
+
+extern "C" int apse_k_undistort_build_map(const UndistortParams* p, void* map, float* lin, hipStream_t s) {
+    hipLaunchKernelGGL(undistort_build_map, dim3((p->W + 255) / 256, p->H), dim3(256), 0, s, *p, reinterpret_cast<int2*>(map), lin);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+
 extern "C" int apse_k_undistort_gamma(const UndistortParams* p, const uint8_t* src, uint8_t* dst, const uint8_t* lut, int B,
                                       hipStream_t s) {
     hipLaunchKernelGGL(undistort_gamma, dim3((p->W + 255) / 256, p->H, B), dim3(256), 0, s, *p, src, dst, lut);

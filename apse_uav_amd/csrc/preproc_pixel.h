@@ -28,25 +28,43 @@ __device__ __forceinline__ int pp_sat8(float v) {
     return r < 0.f ? 0 : (r > 255.f ? 255 : (int)r);
 }
 
-// s: the frame [H][W][3] u8 (BGR); (x, y): destination pixel; out: its three channels
+// Source position of destination pixel (x, y) in 1/32 px: (sx, sy) integer part, (fx, fy) 5-bit fraction.
+__device__ __forceinline__ void undistort_map_pixel(const UndistortParams& p, int x, int y, int& sx, int& sy, int& fx, int& fy) {
+    const double j = (double)x, i = (double)y;
+    const double _x = j * p.ir[0] + (i * p.ir[1] + p.ir[2]);
+    const double _y = j * p.ir[3] + (i * p.ir[4] + p.ir[5]);
+    const double _w = j * p.ir[6] + (i * p.ir[7] + p.ir[8]);
+    const double w = 1.0 / _w;
+    const double xx = _x * w, yy = _y * w;
+    const double x2 = xx * xx, y2 = yy * yy;
+    const double r2 = x2 + y2, _2xy = 2 * xx * yy;
+    const double kr = (1 + ((p.k[4] * r2 + p.k[1]) * r2 + p.k[0]) * r2) / (1 + ((p.k[7] * r2 + p.k[6]) * r2 + p.k[5]) * r2);
+    const double xd = xx * kr + p.k[2] * _2xy + p.k[3] * (r2 + 2 * x2) + p.k[8] * r2 + p.k[9] * r2 * r2;
+    const double yd = yy * kr + p.k[2] * (r2 + 2 * y2) + p.k[3] * _2xy + p.k[10] * r2 + p.k[11] * r2 * r2;
+    const double u = p.fx * xd + p.u0, v = p.fy * yd + p.v0;
+    const long long iu = (long long)rint(u * 32.0), iv = (long long)rint(v * 32.0);
+    // far-away sources (nothing of the frame under the 2x2 footprint) are parked at -2: they read zeros like any border tap
+    const long long qx = iu >> 5, qy = iv >> 5;
+    sx = (qx < -2 || qx > 100000) ? -2 : (int)qx;
+    sy = (qy < -2 || qy > 100000) ? -2 : (int)qy;
+    fx = (int)(iu & 31); fy = (int)(iv & 31);
+}
+
+// s: the frame [H][W][3] u8 (BGR); (x, y): destination pixel; out: its three channels.  map (optional): the camera's remap table
+// [H][W] of (sx, sy << 0 | fractions) built once by apse_set_camera with undistort_map_pixel -- the map depends on the camera
+// only, the f64 rational model per pixel was most of this function's time; lin (optional): srgb_to_lin of the 256 byte values,
+// built on the device with the same powf.
 __device__ __forceinline__ void undistort_gamma_pixel(const UndistortParams& p, const uint8_t* __restrict__ s,
-                                                      const uint8_t* __restrict__ lut, int x, int y, int& c0, int& c1, int& c2) {
+                                                      const uint8_t* __restrict__ lut, int x, int y, int& c0, int& c1, int& c2,
+                                                      const int2* __restrict__ map = nullptr, const float* __restrict__ lin = nullptr) {
     if (p.do_undistort) {
-        const double j = (double)x, i = (double)y;
-        const double _x = j * p.ir[0] + (i * p.ir[1] + p.ir[2]);
-        const double _y = j * p.ir[3] + (i * p.ir[4] + p.ir[5]);
-        const double _w = j * p.ir[6] + (i * p.ir[7] + p.ir[8]);
-        const double w = 1.0 / _w;
-        const double xx = _x * w, yy = _y * w;
-        const double x2 = xx * xx, y2 = yy * yy;
-        const double r2 = x2 + y2, _2xy = 2 * xx * yy;
-        const double kr = (1 + ((p.k[4] * r2 + p.k[1]) * r2 + p.k[0]) * r2) / (1 + ((p.k[7] * r2 + p.k[6]) * r2 + p.k[5]) * r2);
-        const double xd = xx * kr + p.k[2] * _2xy + p.k[3] * (r2 + 2 * x2) + p.k[8] * r2 + p.k[9] * r2 * r2;
-        const double yd = yy * kr + p.k[2] * (r2 + 2 * y2) + p.k[3] * _2xy + p.k[10] * r2 + p.k[11] * r2 * r2;
-        const double u = p.fx * xd + p.u0, v = p.fy * yd + p.v0;
-        const long long iu = (long long)rint(u * 32.0), iv = (long long)rint(v * 32.0);
-        const int sx = (int)(iu >> 5), sy = (int)(iv >> 5);
-        const int fx = (int)(iu & 31), fy = (int)(iv & 31);
+        int sx, sy, fx, fy;
+        if (map) {
+            const int2 mv = map[(size_t)y * p.W + x];
+            sx = mv.x; sy = mv.y >> 10; fx = (mv.y >> 5) & 31; fy = mv.y & 31;
+        } else {
+            undistort_map_pixel(p, x, y, sx, sy, fx, fy);
+        }
         const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
         int acc[3] = {1 << 14, 1 << 14, 1 << 14};
         const bool x0 = (unsigned)sx < (unsigned)p.W, x1 = (unsigned)(sx + 1) < (unsigned)p.W;
@@ -63,7 +81,8 @@ __device__ __forceinline__ void undistort_gamma_pixel(const UndistortParams& p, 
     }
     if (p.do_gamma) {
         // channel 0 plays "R" (the reference converts a BGR frame with COLOR_RGB2LAB)
-        const float R = pp_srgb_to_lin((float)c0 / 255.f), G = pp_srgb_to_lin((float)c1 / 255.f), B = pp_srgb_to_lin((float)c2 / 255.f);
+        const float R = lin ? lin[c0] : pp_srgb_to_lin((float)c0 / 255.f), G = lin ? lin[c1] : pp_srgb_to_lin((float)c1 / 255.f),
+                    B = lin ? lin[c2] : pp_srgb_to_lin((float)c2 / 255.f);
         const float X = (R * 0.412453f + G * 0.357580f + B * 0.180423f) / 0.950456f;
         const float Y = R * 0.212671f + G * 0.715160f + B * 0.072169f;
         const float Z = (R * 0.019334f + G * 0.119193f + B * 0.950227f) / 1.088754f;
