@@ -12,7 +12,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libapse_hip.so")
+# APSE_HIP_LIB: another build of the same sources (A/B measurements of a compile-time switch, tools/gpu_ab.sh); the
+# default is the in-tree library
+LIB_PATH = os.environ.get("APSE_HIP_LIB") or os.path.join(_HERE, "libapse_hip.so")
 
 APSE_OK = 0
 
@@ -91,6 +93,7 @@ def load():
         "apse_conv2d": ([C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, sz, vp], i),
         "apse_maxpool3x3s2": ([vp, vp, i, i, i, i, vp], i),
         "apse_roi_align": ([C.POINTER(vp), C.POINTER(i), C.POINTER(i), vp, i, i, i, vp, vp], i),
+        "apse_roi_align_typed": ([C.POINTER(vp), C.POINTER(i), C.POINTER(i), vp, i, i, i, i, vp, vp], i),
         "apse_roi_pool": ([vp, i, i, vp, vp, i, i, f, vp, vp], i),
         "apse_roi_features": ([vp, i, vp, vp, i, i, vp, vp], i),
         "apse_nms_rank": ([vp, vp, vp, i, i, i, i, f, i, vp, vp, vp, vp, vp], i),
@@ -120,7 +123,7 @@ EXPORTS = ["apse_create", "apse_destroy", "apse_last_error", "apse_version", "ap
            "apse_box_head", "apse_set_detections", "apse_mask_tail", "apse_embed", "apse_forward", "apse_results_describe",
            "apse_read_results", "apse_copy_mask_window", "apse_feature_shape", "apse_export_feature", "apse_debug_tensor",
            "apse_flops", "apse_profile", "apse_profile_read", "apse_conv_packed_elems", "apse_conv_pack_weight", "apse_conv2d", "apse_maxpool3x3s2",
-           "apse_roi_align", "apse_roi_pool", "apse_roi_features", "apse_nms_rank", "apse_mask_centroid_dense", "apse_mask_closest_dense",
+           "apse_roi_align", "apse_roi_align_typed", "apse_roi_pool", "apse_roi_features", "apse_nms_rank", "apse_mask_centroid_dense", "apse_mask_closest_dense",
            "apse_l2_normalize", "apse_sqdist", "apse_undistort_gamma", "apse_resize_normalize", "apse_replay_create", "apse_replay_destroy",
            "apse_replay_step", "apse_replay_packed", "apse_replay_max_id", "apse_replay_next_id"]
 

@@ -91,16 +91,24 @@ __device__ __forceinline__ f32x4 apse_ld4(const void* base, size_t idx, int st) 
 // Layer outputs are written with the nontemporal hint: they are consumed by the NEXT launch (after the end-of-kernel
 // write-back), never by this one, and streaming them keeps the filters / input tiles of the running launch in L2
 // (res4 conv3: 643 -> 622 us per frame; neutral elsewhere).
+#ifndef APSE_NT
+#define APSE_NT 1
+#endif
+#if APSE_NT
+#define APSE_NT_STORE(v, ptr) __builtin_nontemporal_store(v, ptr)
+#else
+#define APSE_NT_STORE(v, ptr) (*(ptr) = (v))
+#endif
 __device__ __forceinline__ void apse_st4(void* base, size_t idx, f32x4 v, int st) {
-    if (st == 0) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx)); return; }
+    if (st == 0) { APSE_NT_STORE(v, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx)); return; }
     if (st == 1) {
         bf16x4_t b;
         b[0] = (__bf16)v[0]; b[1] = (__bf16)v[1]; b[2] = (__bf16)v[2]; b[3] = (__bf16)v[3];
-        __builtin_nontemporal_store(b, reinterpret_cast<bf16x4_t*>(reinterpret_cast<uint16_t*>(base) + idx));
+        APSE_NT_STORE(b, reinterpret_cast<bf16x4_t*>(reinterpret_cast<uint16_t*>(base) + idx));
     } else {
         f16x4_t h;
         h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
-        __builtin_nontemporal_store(h, reinterpret_cast<f16x4_t*>(reinterpret_cast<uint16_t*>(base) + idx));
+        APSE_NT_STORE(h, reinterpret_cast<f16x4_t*>(reinterpret_cast<uint16_t*>(base) + idx));
     }
 }
 // Warm the NEXT layer's filters from this launch: the next launch otherwise starts with every block missing on the

@@ -210,18 +210,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
                 if (m < M) {
                     const size_t yi = (size_t)m * N + nb;
                     if constexpr (PR == 0) {
-                        __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(p.y + yi));
-                        __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(p.y + yi + 4));
+                        APSE_NT_STORE(v0, reinterpret_cast<f32x4*>(p.y + yi));
+                        APSE_NT_STORE(v1, reinterpret_cast<f32x4*>(p.y + yi + 4));
                     } else if constexpr (PR == 1) {
                         bf16x8 o;
                         o[0] = (__bf16)v0[0]; o[1] = (__bf16)v0[1]; o[2] = (__bf16)v0[2]; o[3] = (__bf16)v0[3];
                         o[4] = (__bf16)v1[0]; o[5] = (__bf16)v1[1]; o[6] = (__bf16)v1[2]; o[7] = (__bf16)v1[3];
-                        __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<uint16_t*>(p.y) + yi));
+                        APSE_NT_STORE(o, reinterpret_cast<bf16x8*>(reinterpret_cast<uint16_t*>(p.y) + yi));
                     } else {
                         f16x8 o;
                         o[0] = (_Float16)v0[0]; o[1] = (_Float16)v0[1]; o[2] = (_Float16)v0[2]; o[3] = (_Float16)v0[3];
                         o[4] = (_Float16)v1[0]; o[5] = (_Float16)v1[1]; o[6] = (_Float16)v1[2]; o[7] = (_Float16)v1[3];
-                        __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(reinterpret_cast<uint16_t*>(p.y) + yi));
+                        APSE_NT_STORE(o, reinterpret_cast<f16x8*>(reinterpret_cast<uint16_t*>(p.y) + yi));
                     }
                 }
             }
@@ -432,18 +432,18 @@ __global__ __launch_bounds__(256, NT >= 8 ? 1 : 2) void conv1x1_stream_k(const C
                             if (m < M) {
                                 const size_t yi = (size_t)m * N + nb;
                                 if constexpr (PR == 0) {
-                                    __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(p.y + yi));
-                                    __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(p.y + yi + 4));
+                                    APSE_NT_STORE(v0, reinterpret_cast<f32x4*>(p.y + yi));
+                                    APSE_NT_STORE(v1, reinterpret_cast<f32x4*>(p.y + yi + 4));
                                 } else if constexpr (PR == 1) {
                                     bf16x8 o;
                                     o[0] = (__bf16)v0[0]; o[1] = (__bf16)v0[1]; o[2] = (__bf16)v0[2]; o[3] = (__bf16)v0[3];
                                     o[4] = (__bf16)v1[0]; o[5] = (__bf16)v1[1]; o[6] = (__bf16)v1[2]; o[7] = (__bf16)v1[3];
-                                    __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<uint16_t*>(p.y) + yi));
+                                    APSE_NT_STORE(o, reinterpret_cast<bf16x8*>(reinterpret_cast<uint16_t*>(p.y) + yi));
                                 } else {
                                     f16x8 o;
                                     o[0] = (_Float16)v0[0]; o[1] = (_Float16)v0[1]; o[2] = (_Float16)v0[2]; o[3] = (_Float16)v0[3];
                                     o[4] = (_Float16)v1[0]; o[5] = (_Float16)v1[1]; o[6] = (_Float16)v1[2]; o[7] = (_Float16)v1[3];
-                                    __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(reinterpret_cast<uint16_t*>(p.y) + yi));
+                                    APSE_NT_STORE(o, reinterpret_cast<f16x8*>(reinterpret_cast<uint16_t*>(p.y) + yi));
                                 }
                             }
                         }

@@ -1188,12 +1188,13 @@ int apse_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void
     return apse_k_maxpool3x3s2(x, y, B, H, W, C, 0, (hipStream_t)stream);
 }
 
-int apse_roi_align(const float* const* feats, const int* hs, const int* ws, const float* rois, int n, int per_img, int out_size,
-                   float* out, void* stream) {
+static int roi_align_stateless(const void* const* feats, const int* hs, const int* ws, const float* rois, int n, int per_img,
+                               int out_size, int st, void* out, void* stream) {
+    if (!feats || !hs || !ws || !rois || !out || n < 0 || out_size < 1 || st < 0 || st > 2) return APSE_E_INVALID;
     FpnMaps F;
     static const float sc[4] = {0.25f, 0.125f, 0.0625f, 0.03125f};
     for (int l = 0; l < 4; ++l) { F.p[l] = feats[l]; F.H[l] = hs[l]; F.W[l] = ws[l]; F.scale[l] = sc[l]; }
-    F.st = 0;
+    F.st = st;
     // all rois live: a one-element count array is not available here, so use a device int holding n via total
     static int* total_dev = nullptr;
     if (!total_dev) hipMalloc(reinterpret_cast<void**>(&total_dev), sizeof(int));
@@ -1205,10 +1206,20 @@ int apse_roi_align(const float* const* feats, const int* hs, const int* ws, cons
     int* img_dev = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&img_dev), sizeof(int) * (n > 0 ? n : 1)) != hipSuccess) return APSE_E_NOMEM;
     hipMemcpy(img_dev, img.data(), sizeof(int) * n, hipMemcpyHostToDevice);
-    int rc = apse_k_roi_align(&F, rois, img_dev, nullptr, total_dev, 0, n, out_size, out, 0, (hipStream_t)stream);
+    int rc = apse_k_roi_align(&F, rois, img_dev, nullptr, total_dev, 0, n, out_size, out, st, (hipStream_t)stream);
     hipStreamSynchronize((hipStream_t)stream);
     hipFree(img_dev);
     return rc;
+}
+
+int apse_roi_align(const float* const* feats, const int* hs, const int* ws, const float* rois, int n, int per_img, int out_size,
+                   float* out, void* stream) {
+    return roi_align_stateless(reinterpret_cast<const void* const*>(feats), hs, ws, rois, n, per_img, out_size, 0, out, stream);
+}
+
+int apse_roi_align_typed(const void* const* feats, const int* hs, const int* ws, const float* rois, int n, int per_img,
+                         int out_size, int storage, void* out, void* stream) {
+    return roi_align_stateless(feats, hs, ws, rois, n, per_img, out_size, storage, out, stream);
 }
 
 int apse_roi_pool(const float* feat, int H, int W, const float* rois, const int* roi_img, int n, int out_size, float scale,

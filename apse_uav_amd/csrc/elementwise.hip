@@ -8,6 +8,8 @@
 #include "apse_common.h"
 #include "preproc_pixel.h"
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define PIL_PRECISION_BITS 22
 
@@ -23,14 +25,9 @@ __device__ __forceinline__ int clip8(int v) {
 // the reference's preprocess_img) -- so a pre-processed 4K frame is never written to / re-read from HBM (2 x 24.9 MB per frame
 // and one launch less than undistort_gamma -> pil_resize_h).  Same per-pixel function, same bytes as the two-kernel form.
 template <bool FUSED>
-__global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp,
-                                                    const int* __restrict__ bounds, const int* __restrict__ coef,
-                                                    int H, int W, int OW, int ksize, size_t src_img_stride,
-                                                    size_t tmp_img_stride, const UndistortParams cam, const uint8_t* __restrict__ lut,
-                                                    const int2* __restrict__ cam_map, const float* __restrict__ cam_lin) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint8_t* row = reinterpret_cast<uint8_t*>(smem);
-    const int y = blockIdx.x, b = blockIdx.y;
+__device__ __forceinline__ void pil_stage_row(uint8_t* row, const uint8_t* __restrict__ src, int y, int b, int W, size_t src_img_stride,
+                                              const UndistortParams& cam, const uint8_t* __restrict__ lut,
+                                              const int2* __restrict__ cam_map, const float* __restrict__ cam_lin) {
     const uint8_t* srow = src + (size_t)b * src_img_stride + (size_t)y * W * 3;
     const int nbytes = W * 3;
     if constexpr (FUSED) {
@@ -51,6 +48,19 @@ __global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ 
         uint32_t* r4 = reinterpret_cast<uint32_t*>(row);
         for (int i = threadIdx.x; i < (nbytes >> 2); i += blockDim.x) r4[i] = s4[i];
     }
+}
+
+// Any filter length: each thread produces output samples (ox, c) one after the other.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp,
+                                                    const int* __restrict__ bounds, const int* __restrict__ coef,
+                                                    int H, int W, int OW, int ksize, size_t src_img_stride,
+                                                    size_t tmp_img_stride, const UndistortParams cam, const uint8_t* __restrict__ lut,
+                                                    const int2* __restrict__ cam_map, const float* __restrict__ cam_lin) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t* row = reinterpret_cast<uint8_t*>(smem);
+    const int y = blockIdx.x, b = blockIdx.y;
+    pil_stage_row<FUSED>(row, src, y, b, W, src_img_stride, cam, lut, cam_map, cam_lin);
     __syncthreads();
     uint8_t* orow = tmp + (size_t)b * tmp_img_stride + (size_t)y * OW * 3;
     for (int o = threadIdx.x; o < OW * 3; o += blockDim.x) {
@@ -61,6 +71,70 @@ __global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ 
         for (int j = 0; j < cnt; ++j) ss += (int)row[(xmin + j) * 3 + c] * k[j];
         orow[o] = (uint8_t)clip8(ss);
     }
+}
+
+// Filters of at most 8 taps (every downscale up to 3.5x, e.g. 3840 -> 1344): the form above is bound by its chain of dependent
+// loads (bounds -> filter taps -> LDS, once per output sample: ~16 samples x 2 round trips per thread, 43 us per 4K frame
+// for 25 MB).  Here a thread owns output pixel ox = tid + 256 i with its three channels, and the bounds and the 8 tap
+// slots of TWO pixels are requested together (their addresses depend on ox only; slots past the pixel's count read as 0),
+// so a block makes ~3 round trips instead of ~32.  The output row is collected in LDS and leaves in 16-byte stores.
+// Same integer arithmetic in the same order: bit-identical output.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void pil_resize_h8(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp,
+                                                     const int2* __restrict__ bounds, const int* __restrict__ coef,
+                                                     int H, int W, int OW, int ksize, size_t src_img_stride,
+                                                     size_t tmp_img_stride, const UndistortParams cam, const uint8_t* __restrict__ lut,
+                                                     const int2* __restrict__ cam_map, const float* __restrict__ cam_lin) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t* row = reinterpret_cast<uint8_t*>(smem);                      // W*3 bytes (+ 32: tap slots past the row end)
+    const int y = blockIdx.x, b = blockIdx.y;
+    uint8_t* gdst = tmp + (size_t)b * tmp_img_stride + (size_t)y * OW * 3;
+    // the output row sits in LDS at the same offset mod 16 as its destination, so the 16-byte body of the copy-out is
+    // aligned on both sides whatever OW is (1333 * 3 bytes per row: rows start at every alignment)
+    const int mis = (int)(reinterpret_cast<uintptr_t>(gdst) & 15);
+    uint8_t* orow_l = row + (((size_t)W * 3 + 32 + 15) & ~(size_t)15) + mis;    // OW*3 bytes
+    pil_stage_row<FUSED>(row, src, y, b, W, src_img_stride, cam, lut, cam_map, cam_lin);
+    if (threadIdx.x < 32) row[W * 3 + threadIdx.x] = 0;
+    __syncthreads();
+    for (int ox0 = threadIdx.x; ox0 < OW; ox0 += 512) {
+        int2 bd[2];
+        int k[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ox = ox0 + 256 * u;
+            const bool in = ox < OW;
+            bd[u] = in ? bounds[ox] : int2{0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) k[u][j] = (in && j < ksize) ? coef[ox * ksize + j] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ox = ox0 + 256 * u;
+            if (ox >= OW) break;
+            const uint8_t* px = row + bd[u].x * 3;
+            int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = j < bd[u].y ? k[u][j] : 0;
+                s0 += (int)px[j * 3 + 0] * kk;
+                s1 += (int)px[j * 3 + 1] * kk;
+                s2 += (int)px[j * 3 + 2] * kk;
+            }
+            orow_l[ox * 3 + 0] = (uint8_t)clip8(s0);
+            orow_l[ox * 3 + 1] = (uint8_t)clip8(s1);
+            orow_l[ox * 3 + 2] = (uint8_t)clip8(s2);
+        }
+    }
+    __syncthreads();
+    const int nbytes = OW * 3;
+    int head = (16 - mis) & 15;
+    head = head < nbytes ? head : nbytes;
+    const int n16 = (nbytes - head) >> 4;
+    if ((int)threadIdx.x < head) gdst[threadIdx.x] = orow_l[threadIdx.x];
+    uint4* g16 = reinterpret_cast<uint4*>(gdst + head);
+    const uint4* l16 = reinterpret_cast<const uint4*>(orow_l + head);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) g16[i] = l16[i];
+    for (int i = head + n16 * 16 + threadIdx.x; i < nbytes; i += blockDim.x) gdst[i] = orow_l[i];
 }
 
 // Network input layouts (both zeroed once at allocation; only the OH x OW interior and the 3 real channels are ever written):
@@ -204,14 +278,25 @@ int apse_k_pil_resize(const uint8_t* src, uint8_t* tmp, void* out, int out_st, u
     if ((W & 3) != 0 || (size_t)W * 3 > 150000) return APSE_E_INVALID;
     UndistortParams none;
     memset(&none, 0, sizeof none);
-    if (cam && (cam->do_undistort || cam->do_gamma)) {
-        if (cam->H != H || cam->W != W) return APSE_E_INVALID;
+    const bool fused = cam && (cam->do_undistort || cam->do_gamma);
+    if (fused && (cam->H != H || cam->W != W)) return APSE_E_INVALID;
+    // at most 8 taps: the batched form
+    const bool h8 = hk <= 8 && (reinterpret_cast<uintptr_t>(hb) & 7) == 0;
+    const size_t lds8 = (((size_t)W * 3 + 32 + 15) & ~(size_t)15) + (size_t)OW * 3 + 32;
+    const int2* hb2 = reinterpret_cast<const int2*>(hb);
+    const int2* map2 = reinterpret_cast<const int2*>(cam_map);
+    if (h8 && fused)
+        hipLaunchKernelGGL(pil_resize_h8<true>, dim3(H, B), dim3(256), lds8, s, src, tmp, hb2, hc, H, W, OW, hk, (size_t)H * W * 3,
+                           (size_t)H * OW * 3, *cam, lut, map2, cam_lin);
+    else if (h8)
+        hipLaunchKernelGGL(pil_resize_h8<false>, dim3(H, B), dim3(256), lds8, s, src, tmp, hb2, hc, H, W, OW, hk, (size_t)H * W * 3,
+                           (size_t)H * OW * 3, none, nullptr, nullptr, nullptr);
+    else if (fused)
         hipLaunchKernelGGL(pil_resize_h<true>, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
-                           (size_t)H * W * 3, (size_t)H * OW * 3, *cam, lut, reinterpret_cast<const int2*>(cam_map), cam_lin);
-    } else {
+                           (size_t)H * W * 3, (size_t)H * OW * 3, *cam, lut, map2, cam_lin);
+    else
         hipLaunchKernelGGL(pil_resize_h<false>, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
                            (size_t)H * W * 3, (size_t)H * OW * 3, none, nullptr, nullptr, nullptr);
-    }
     hipLaunchKernelGGL(pil_resize_v_norm, dim3((OW * 3 + 255) / 256, OH, B), dim3(256), 0, s, tmp, out, out_st, vb, vc, OH, OW, vk,
                        PH, PW, mean[0], mean[1], mean[2], (size_t)H * OW * 3, resized_u8);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;

@@ -17,49 +17,91 @@ struct FpnMaps {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// One wave per output bin.  rois: [n_max][4]; image of roi r: roi_img ? roi_img[r] : r / per_img.
+// ---- ROIAlign ----------------------------------------------------------------------------------------------------------
+// One block per roi, one wave per output bin.  rois: [n_max][4]; image of roi r: roi_img ? roi_img[r] : r / per_img.
 // live rois: (roi_img ? r < *total : (r % per_img) < cnt[r / per_img]); dead rois write zeros.
-__global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const float* __restrict__ rois,
-                                                      const int* __restrict__ roi_img, const int* __restrict__ cnt,
-                                                      const int* __restrict__ total, int per_img, int n_max, int R,
-                                                      void* __restrict__ out, int out_st) {
-    const int lane = threadIdx.x & 63;
-    const int rr = R * R;
-    const int nlive = roi_img ? (*total < n_max ? *total : n_max) : n_max;
-    for (int bin = blockIdx.x * 4 + (threadIdx.x >> 6); bin < nlive * rr; bin += gridDim.x * 4) {
-    const int r = bin / rr;
-    const int pb = bin - r * rr;
-    const int ph = pb / R, pw = pb - ph * R;
-    int img;
-    bool live;
-    if (roi_img) {
-        live = r < *total;
-        img = live ? roi_img[r] : 0;
+//
+// A bin averages gh x gw bilinear samples (adaptive grid: g = ceil(roi extent / R)), 4 taps each.  The sample grid is a
+// product grid and the clamp / skip rules act per axis, so the sum is separable:
+//     sum_iy sum_ix bilinear(y_iy, x_ix) = sum_Y sum_X wy[Y] wx[X] F[Y][X],
+// wy[Y] = sum of the row weights (hy or ly) the samples put on map row Y, wx likewise.  Neighbouring samples are at most
+// one cell apart, so the taps cover a contiguous (<= gh + 1) x (<= gw + 1) window: a 4 x 4 grid reads 25 cells instead
+// of 64 taps.  Windows of at most RA_CAP cells per axis (larger ones -- boxes that are long and thin on a fine level --
+// take the per-sample loop).  16-bit maps: a cell's 256 channels are 512 B, so the
+// two half-waves take alternate cells of the window with 16 B per lane and are added at the end.
+// f32 sums in a fixed order: (Y, X) row-major per half-wave.
+#define RA_CAP 16
+#define RA_FLIGHT 8        // cell loads requested together per lane (the kernel is latency- / L2-bandwidth-bound)
+
+struct RaAxis { int base, n; float w; bool ok; };
+
+// taps of one axis of one bin: s0 = roi start (map cells, -0.5 shifted), pi = bin index, bsz = bin size, g = samples, L = map extent
+__device__ __forceinline__ RaAxis ra_axis(float s0, int pi, float bsz, int g, int L, int lane) {
+    RaAxis a;
+    int lo = 0x7fffffff, hi = -1;
+    for (int i = 0; i < g; ++i) {
+        float v = s0 + (float)pi * bsz + ((float)i + 0.5f) * bsz / (float)g;
+        if (v < -1.0f || v > (float)L) continue;
+        if (v <= 0.f) v = 0.f;
+        int l = (int)v, h;
+        if (l >= L - 1) { h = l = L - 1; } else { h = l + 1; }
+        lo = l < lo ? l : lo; hi = h > hi ? h : hi;
+    }
+    a.base = lo; a.n = hi < 0 ? 0 : hi - lo + 1; a.w = 0.f;
+    a.ok = a.n <= RA_CAP;
+    if (!a.ok || a.n == 0) return a;
+    for (int i = 0; i < g; ++i) {
+        float v = s0 + (float)pi * bsz + ((float)i + 0.5f) * bsz / (float)g;
+        if (v < -1.0f || v > (float)L) continue;
+        if (v <= 0.f) v = 0.f;
+        int l = (int)v, h;
+        if (l >= L - 1) { h = l = L - 1; v = (float)l; } else { h = l + 1; }
+        const float lv = v - (float)l, hv = 1.f - lv;
+        if (l - lo == lane) a.w += hv;
+        if (h - lo == lane) a.w += lv;
+    }
+    return a;
+}
+
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x8 ra_cvt8(const uint4 raw, int st) {       // 8 consecutive 16-bit channels -> f32
+    f32x8 r;
+    if (st == 1) {
+        r[0] = __uint_as_float(raw.x << 16); r[1] = __uint_as_float(raw.x & 0xffff0000u);
+        r[2] = __uint_as_float(raw.y << 16); r[3] = __uint_as_float(raw.y & 0xffff0000u);
+        r[4] = __uint_as_float(raw.z << 16); r[5] = __uint_as_float(raw.z & 0xffff0000u);
+        r[6] = __uint_as_float(raw.w << 16); r[7] = __uint_as_float(raw.w & 0xffff0000u);
     } else {
-        img = r / per_img;
-        live = (r - img * per_img) < cnt[img];
+        f16x8_t h;
+        __builtin_memcpy(&h, &raw, 16);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = (float)h[k];
     }
-    const size_t o = ((size_t)r * rr + pb) * 256 + lane * 4;
-    if (!live) {
-        if (!roi_img) apse_st4(out, o, f32x4{0.f, 0.f, 0.f, 0.f}, out_st);
-        continue;                         // packed list: rows past the count are never read
+    return r;
+}
+
+__device__ __forceinline__ void ra_st8(void* base, size_t idx, const f32x8& v, int st) {
+    if (st == 0) {
+        apse_st4(base, idx, f32x4{v[0], v[1], v[2], v[3]}, 0);
+        apse_st4(base, idx + 4, f32x4{v[4], v[5], v[6], v[7]}, 0);
+    } else if (st == 1) {
+        bf16x8 b;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b[k] = (__bf16)v[k];
+        APSE_NT_STORE(b, reinterpret_cast<bf16x8*>(reinterpret_cast<uint16_t*>(base) + idx));
+    } else {
+        f16x8_t h;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] = (_Float16)v[k];
+        APSE_NT_STORE(h, reinterpret_cast<f16x8_t*>(reinterpret_cast<uint16_t*>(base) + idx));
     }
-    const float x1 = rois[r * 4 + 0], y1 = rois[r * 4 + 1], x2 = rois[r * 4 + 2], y2 = rois[r * 4 + 3];
-    // assign_boxes_to_levels: floor(4 + log2(sqrt(area) / 224 + eps)), clamped to [2, 5]
-    const float sz = sqrtf((x2 - x1) * (y2 - y1));
-    float lvf = floorf(4.0f + log2f(sz / 224.0f + 2.220446049250313e-16f));
-    lvf = fminf(fmaxf(lvf, 2.f), 5.f);
-    const int lv = (int)lvf - 2;
-    const int H = F.H[lv], W = F.W[lv];
-    const float sc = F.scale[lv];
-    const void* fmap = F.p[lv];
-    const size_t f = (size_t)img * H * W * 256 + lane * 4;
-    const float sw = x1 * sc - 0.5f, sh = y1 * sc - 0.5f;
-    const float ew = x2 * sc - 0.5f, eh = y2 * sc - 0.5f;
-    const float rw = ew - sw, rh = eh - sh;
-    const float bw = rw / (float)R, bh = rh / (float)R;
-    const int gh = (int)ceilf(rh / (float)R), gw = (int)ceilf(rw / (float)R);
-    const float cntf = (float)((gh * gw) > 1 ? gh * gw : 1);
+}
+
+// the per-sample form (any window size); also the statement the separable form is derived from
+__device__ __forceinline__ f32x4 ra_bin_direct(const void* fmap, int st, size_t f, int H, int W, float sh, float sw, float bh,
+                                                float bw, int gh, int gw, int ph, int pw) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int iy = 0; iy < gh; ++iy) {
         float y = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
@@ -76,14 +118,140 @@ __global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const flo
             if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
             const float lx = x - (float)xl, hx = 1.f - lx;
             const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-            const f32x4 v1 = apse_ld4(fmap, f + ((size_t)yl * W + xl) * 256, F.st);
-            const f32x4 v2 = apse_ld4(fmap, f + ((size_t)yl * W + xh) * 256, F.st);
-            const f32x4 v3 = apse_ld4(fmap, f + ((size_t)yh * W + xl) * 256, F.st);
-            const f32x4 v4 = apse_ld4(fmap, f + ((size_t)yh * W + xh) * 256, F.st);
+            const f32x4 v1 = apse_ld4(fmap, f + ((size_t)yl * W + xl) * 256, st);
+            const f32x4 v2 = apse_ld4(fmap, f + ((size_t)yl * W + xh) * 256, st);
+            const f32x4 v3 = apse_ld4(fmap, f + ((size_t)yh * W + xl) * 256, st);
+            const f32x4 v4 = apse_ld4(fmap, f + ((size_t)yh * W + xh) * 256, st);
             acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
         }
     }
-    apse_st4(out, o, acc / cntf, out_st);
+    return acc;
+}
+
+#define RA_MAXR 14          // largest pooler resolution (mask head)
+
+template <bool ST16>
+__global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const float* __restrict__ rois,
+                                                      const int* __restrict__ roi_img, const int* __restrict__ cnt,
+                                                      const int* __restrict__ total, int per_img, int n_max, int R,
+                                                      void* __restrict__ out, int out_st) {
+    // One block per roi: the tap tables of its R row bins and R column bins are built once, 16 lanes per (axis, bin) --
+    // per bin this arithmetic is wave-uniform and would otherwise be repeated by all 64 lanes of all R*R bin waves
+    // (it was 2/3 of the kernel's instructions) -- then the four waves take the R*R bins round-robin.
+    __shared__ float wtab[2][RA_MAXR][RA_CAP];
+    __shared__ int btab[2][RA_MAXR][2];
+    __shared__ int all_ok;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rr = R * R;
+    const int nlive = roi_img ? (*total < n_max ? *total : n_max) : n_max;
+    for (int r = blockIdx.x; r < nlive; r += gridDim.x) {
+    int img;
+    bool live;
+    if (roi_img) {
+        live = r < *total;
+        img = live ? roi_img[r] : 0;
+    } else {
+        img = r / per_img;
+        live = (r - img * per_img) < cnt[img];
+    }
+    if (!live) {
+        if (!roi_img)
+            for (int pb = wave; pb < rr; pb += 4) apse_st4(out, ((size_t)r * rr + pb) * 256 + lane * 4, f32x4{0.f, 0.f, 0.f, 0.f}, out_st);
+        continue;                         // packed list: rows past the count are never read
+    }
+    const float x1 = rois[r * 4 + 0], y1 = rois[r * 4 + 1], x2 = rois[r * 4 + 2], y2 = rois[r * 4 + 3];
+    // assign_boxes_to_levels: floor(4 + log2(sqrt(area) / 224 + eps)), clamped to [2, 5]
+    const float sz = sqrtf((x2 - x1) * (y2 - y1));
+    float lvf = floorf(4.0f + log2f(sz / 224.0f + 2.220446049250313e-16f));
+    lvf = fminf(fmaxf(lvf, 2.f), 5.f);
+    const int lv = (int)lvf - 2;
+    const int H = F.H[lv], W = F.W[lv];
+    const float sc = F.scale[lv];
+    const void* fmap = F.p[lv];
+    const size_t fimg = (size_t)img * H * W * 256;
+    const float sw = x1 * sc - 0.5f, sh = y1 * sc - 0.5f;
+    const float ew = x2 * sc - 0.5f, eh = y2 * sc - 0.5f;
+    const float rw = ew - sw, rh = eh - sh;
+    const float bw = rw / (float)R, bh = rh / (float)R;
+    const int gh = (int)ceilf(rh / (float)R), gw = (int)ceilf(rw / (float)R);
+    const float cntf = (float)((gh * gw) > 1 ? gh * gw : 1);
+    __syncthreads();                      // the previous roi's tables are no longer read
+    if (threadIdx.x == 0) all_ok = 1;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * R * RA_CAP; e += blockDim.x) {
+        const int axis = e / (R * RA_CAP), b = (e / RA_CAP) % R, c = e & (RA_CAP - 1);
+        const RaAxis a = axis == 0 ? ra_axis(sh, b, bh, gh, H, c) : ra_axis(sw, b, bw, gw, W, c);
+        wtab[axis][b][c] = a.w;
+        if (c == 0) { btab[axis][b][0] = a.base; btab[axis][b][1] = a.n; if (!a.ok) all_ok = 0; }
+    }
+    __syncthreads();
+    const bool sep = all_ok != 0;
+    for (int pb = wave; pb < rr; pb += 4) {
+    const int ph = pb / R, pw = pb - ph * R;
+    const size_t o = ((size_t)r * rr + pb) * 256 + lane * 4;
+    if (!sep) {
+        const f32x4 acc = ra_bin_direct(fmap, F.st, fimg + lane * 4, H, W, sh, sw, bh, bw, gh, gw, ph, pw);
+        apse_st4(out, o, acc / cntf, out_st);
+        continue;
+    }
+    const int ybase = btab[0][ph][0], ny = btab[0][ph][1], xbase = btab[1][pw][0], nx = btab[1][pw][1];
+    const float* wyv = wtab[0][ph];
+    const float* wxv = wtab[1][pw];
+    if constexpr (!ST16) {
+        // f32 maps: one cell = 64 lanes x 16 B
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int T = ny * nx;
+        const size_t f0 = fimg + ((size_t)ybase * W + xbase) * 256 + lane * 4;
+        int yy = 0, xx = 0;                                  // window cell of element t, advanced with t
+        for (int t0 = 0; t0 < T; t0 += RA_FLIGHT) {
+            f32x4 v[RA_FLIGHT];
+            float w[RA_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < RA_FLIGHT; ++u) {
+                const bool in = yy < ny;
+                w[u] = in ? wyv[in ? yy : 0] * wxv[xx] : 0.f;
+                v[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(fmap) + f0 + ((size_t)(in ? yy : 0) * W + xx) * 256);
+                if (++xx == nx) { xx = 0; ++yy; }
+            }
+#pragma unroll
+            for (int u = 0; u < RA_FLIGHT; ++u) acc += w[u] * v[u];
+        }
+        apse_st4(out, o, acc / cntf, out_st);
+    } else {
+        // 16-bit maps: half-wave h takes the cells with (X & 1) == h, 32 lanes x 16 B each
+        const int half = lane >> 5, cg = lane & 31;
+        const int np = (nx + 1) >> 1;                       // cell pairs per window row
+        const int T = ny * np;
+        const size_t f0 = fimg + ((size_t)ybase * W + xbase) * 256 + cg * 8;
+        f32x8 acc;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        int yy = 0, xp = 0;
+        for (int t0 = 0; t0 < T; t0 += RA_FLIGHT) {
+            uint4 raw[RA_FLIGHT];                            // RA_FLIGHT cell loads in flight per lane, converted when consumed
+            float w[RA_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < RA_FLIGHT; ++u) {
+                const int xx = 2 * xp + half;
+                const bool in = yy < ny && xx < nx;
+                w[u] = in ? wyv[in ? yy : 0] * wxv[in ? xx : 0] : 0.f;
+                raw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(fmap) + f0 +
+                                                         ((size_t)(in ? yy : 0) * W + (in ? xx : 0)) * 256);
+                if (++xp == np) { xp = 0; ++yy; }
+            }
+#pragma unroll
+            for (int u = 0; u < RA_FLIGHT; ++u) {
+                const f32x8 v = ra_cvt8(raw[u], F.st);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += w[u] * v[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = (acc[k] + __shfl_xor(acc[k], 32)) / cntf;
+        if (half == 0) ra_st8(out, ((size_t)r * rr + pb) * 256 + cg * 8, acc, out_st);
+    }
+    }
     }
 }
 
@@ -240,10 +408,11 @@ __global__ __launch_bounds__(64) void sqdist_matrix(const float* __restrict__ a,
 extern "C" {
 int apse_k_roi_align(const FpnMaps* F, const float* rois, const int* roi_img, const int* cnt, const int* total, int per_img,
                      int n_max, int R, void* out, int out_st, hipStream_t s) {
-    int blocks = (n_max * R * R + 3) / 4;
+    if (R > RA_MAXR || n_max <= 0) return n_max <= 0 ? APSE_OK : APSE_E_INVALID;
+    int blocks = n_max;
     if (roi_img && blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(roi_align_nhwc, dim3(blocks), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R,
-                       out, out_st);
+    if (F->st) hipLaunchKernelGGL(roi_align_nhwc<true>, dim3(blocks), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R, out, out_st);
+    else hipLaunchKernelGGL(roi_align_nhwc<false>, dim3(blocks), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R, out, out_st);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_roi_pool(const void* feat, int st, int H, int W, const float* rois, const int* roi_img, const int* total, int n_max,

@@ -187,6 +187,10 @@ int apse_maxpool3x3s2(const float* x_dev, float* y_dev, int B, int H, int W, int
 /* ROIAlignV2 over 4 levels (NHWC, C = 256); rois [n][4], batch index roi/per_img, all rois live. */
 int apse_roi_align(const float* const* feats_dev, const int* hs, const int* ws, const float* rois_dev, int n, int per_img,
                    int out_size, float* out_dev, void* stream);
+/* Same with the maps and the output in a storage type (0 f32, 1 bf16, 2 f16): the form the 16-bit modes run (two map cells
+   per load instruction); arithmetic is f32 either way. */
+int apse_roi_align_typed(const void* const* feats_dev, const int* hs, const int* ws, const float* rois_dev, int n, int per_img,
+                         int out_size, int storage, void* out_dev, void* stream);
 int apse_roi_pool(const float* feat_dev, int H, int W, const float* rois_dev, const int* roi_img_dev, int n, int out_size,
                   float scale, float* out_dev, void* stream);
 /* Generic per-category NMS + ranking on [n] boxes (category = cat_dev[i] given as entry % cat_mod or / cat_div). */

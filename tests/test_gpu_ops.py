@@ -330,8 +330,9 @@ def test_roi_align_parity(logdir):
                          (cy + bh / 2).clamp(0, 192)], dim=1)
     boxes[0] = torch.tensor([0., 0., 336., 192.])
     boxes[1] = torch.tensor([10., 10., 10.5, 10.2])
-    boxes[2] = torch.tensor([0., 80., 336., 108.])        # wide and flat on the finest level: its cell window exceeds the LDS
-    boxes[3] = torch.tensor([-20., -30., 40., 25.])       # budget of roi_align_lds (direct-load path); samples left / above the map
+    boxes[2] = torch.tensor([0., 80., 336., 108.])        # wide and flat on the finest level: 13 samples per bin across, a
+    #                                                       tap window wider than RA_CAP cells -> the per-sample loop
+    boxes[3] = torch.tensor([-20., -30., 40., 25.])       # samples left of / above the map
     boxes[4] = torch.tensor([300., 170., 400., 260.])     # samples right of / below the map
     for R in (7, 14):
         ref = ops.roi_pooler([f[0] for f in feats], boxes, R)
@@ -346,6 +347,47 @@ def test_roi_align_parity(logdir):
         st = err_stats(out.cpu().permute(0, 3, 1, 2), ref)
         _log(logdir, "roi_align/%d" % R, st)
         assert st["nan"] == 0 and st["max_abs"] < 1e-4, st       # f32, bilinear weights: order-of-sum noise
+
+
+@pytest.mark.parametrize("st,dtype", [(1, torch.bfloat16), (2, torch.float16)])
+def test_roi_align_16bit_maps(logdir, st, dtype):
+    """The form the 16-bit modes run (maps and output stored as bf16 / f16, two map cells per load, f32 arithmetic):
+    equal to the oracle on the SAME rounded maps up to the rounding of the 16-bit output."""
+    from oracle import ops
+    from apse_uav_amd import _lib
+    from hip_helpers import to_nhwc
+    g = torch.Generator().manual_seed(5)
+    sizes = [(48, 84), (24, 42), (12, 21), (6, 11)]
+    feats = [torch.randn(2, 256, h, w, generator=g).to(dtype) for h, w in sizes]
+    per = 150
+    n = 2 * per
+    cx = torch.rand(n, generator=g) * 330
+    cy = torch.rand(n, generator=g) * 190
+    bw = torch.rand(n, generator=g) ** 2 * 300 + 1
+    bh = torch.rand(n, generator=g) ** 2 * 180 + 1
+    boxes = torch.stack([(cx - bw / 2).clamp(0, 336), (cy - bh / 2).clamp(0, 192), (cx + bw / 2).clamp(0, 336),
+                         (cy + bh / 2).clamp(0, 192)], dim=1)
+    boxes[0] = torch.tensor([0., 0., 336., 192.])
+    boxes[1] = torch.tensor([10., 10., 10.5, 10.2])         # one sample per bin, window of 1-2 cells (odd tail of a half-wave)
+    boxes[2] = torch.tensor([0., 80., 336., 108.])          # per-sample loop
+    boxes[per] = torch.tensor([-20., -30., 40., 25.])
+    boxes[per + 1] = torch.tensor([300., 170., 400., 260.])
+    fd = [to_nhwc(f.float()).to(dtype).cuda().contiguous() for f in feats]
+    ptrs = (C.c_void_p * 4)(*[f.data_ptr() for f in fd])
+    hs = (C.c_int * 4)(*[s_[0] for s_ in sizes])
+    ws = (C.c_int * 4)(*[s_[1] for s_ in sizes])
+    bd = boxes.cuda().contiguous()
+    for R in (7, 14):
+        ref = torch.cat([ops.roi_pooler([f[b].float() for f in feats], boxes[b * per:(b + 1) * per], R) for b in range(2)])
+        out = torch.full((n, R, R, 256), float("nan"), device="cuda", dtype=dtype)
+        assert _lib.load().apse_roi_align_typed(ptrs, hs, ws, _lib.ptr(bd), n, per, R, st, _lib.ptr(out), _lib.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        got = out.cpu().float().permute(0, 3, 1, 2)
+        assert not torch.isnan(got).any()
+        ulp = 2.0 ** (-7 if st == 1 else -10)               # bf16: 8 significand bits, f16: 11
+        err = ((got - ref).abs() / ref.abs().clamp_min(0.25)).max().item()
+        _log(logdir, "roi_align16/%d/%d" % (st, R), dict(max_rel=err))
+        assert err <= 0.51 * ulp * 1.05 + 1e-5, err           # half an ulp of the stored type (+ order-of-sum noise)
 
 
 def test_roi_pool_parity(logdir):
