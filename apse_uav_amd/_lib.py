@@ -87,11 +87,12 @@ def load():
         "apse_debug_tensor": ([vp, C.c_char_p, vp, sz, C.POINTER(sz), vp], i),
         "apse_flops": ([vp, i, C.c_double, C.c_double], C.c_double),
         "apse_profile": ([vp, i], i),
-        "apse_profile_read": ([vp, C.POINTER(C.c_double * 36), i], i),
+        "apse_profile_read": ([vp, C.POINTER(C.c_double * 39), i], i),
         "apse_conv_packed_elems": ([C.POINTER(ConvDesc)], sz),
         "apse_conv_pack_weight": ([C.POINTER(ConvDesc), vp, i, vp, vp], i),
         "apse_conv2d": ([C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, sz, vp], i),
         "apse_maxpool3x3s2": ([vp, vp, i, i, i, i, vp], i),
+        "apse_maxpool3x3s2_typed": ([vp, vp, i, i, i, i, i, vp], i),
         "apse_roi_align": ([C.POINTER(vp), C.POINTER(i), C.POINTER(i), vp, i, i, i, vp, vp], i),
         "apse_roi_align_typed": ([C.POINTER(vp), C.POINTER(i), C.POINTER(i), vp, i, i, i, i, vp, vp], i),
         "apse_roi_pool": ([vp, i, i, vp, vp, i, i, f, vp, vp], i),
@@ -123,7 +124,7 @@ EXPORTS = ["apse_create", "apse_destroy", "apse_last_error", "apse_version", "ap
            "apse_box_head", "apse_set_detections", "apse_mask_tail", "apse_embed", "apse_forward", "apse_results_describe",
            "apse_read_results", "apse_copy_mask_window", "apse_feature_shape", "apse_export_feature", "apse_debug_tensor",
            "apse_flops", "apse_profile", "apse_profile_read", "apse_conv_packed_elems", "apse_conv_pack_weight", "apse_conv2d", "apse_maxpool3x3s2",
-           "apse_roi_align", "apse_roi_align_typed", "apse_roi_pool", "apse_roi_features", "apse_nms_rank", "apse_mask_centroid_dense", "apse_mask_closest_dense",
+           "apse_maxpool3x3s2_typed", "apse_roi_align", "apse_roi_align_typed", "apse_roi_pool", "apse_roi_features", "apse_nms_rank", "apse_mask_centroid_dense", "apse_mask_closest_dense",
            "apse_l2_normalize", "apse_sqdist", "apse_undistort_gamma", "apse_resize_normalize", "apse_replay_create", "apse_replay_destroy",
            "apse_replay_step", "apse_replay_packed", "apse_replay_max_id", "apse_replay_next_id"]
 

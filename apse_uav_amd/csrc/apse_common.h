@@ -59,7 +59,8 @@ int apse_launch_conv_bf16(const ConvParams& p, int cfg, hipStream_t s);   // con
 #define APSE_CFG_STREAM 9
 #define APSE_CFG_STREAM_K 10
 #define APSE_CFG_GLDS 11             // conv_glds16.hip: 256x128 tile, 16-bit operands, LDS-DMA ring
-#define APSE_NCFG 12
+#define APSE_CFG_STEMPOOL 12         // stem_pool16.hip: stem convolution + ReLU + max-pool of the 16-bit modes (profile label only)
+#define APSE_NCFG 13
 bool apse_conv1x1_stream_ok(const ConvParams& p);
 int apse_launch_conv1x1_stream(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 bool apse_conv1x1_stream_k_ok(const ConvParams& p);
@@ -132,6 +133,43 @@ __device__ __forceinline__ void apse_warm_retire(ApseWarm& wv) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wv.v[i]));
 }
+// ---- 8 consecutive 16-bit channels (16 bytes) <-> f32
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x8 apse_cvt8(const uint4 raw, int st) {       // 8 consecutive 16-bit channels -> f32
+    f32x8 r;
+    if (st == 1) {
+        r[0] = __uint_as_float(raw.x << 16); r[1] = __uint_as_float(raw.x & 0xffff0000u);
+        r[2] = __uint_as_float(raw.y << 16); r[3] = __uint_as_float(raw.y & 0xffff0000u);
+        r[4] = __uint_as_float(raw.z << 16); r[5] = __uint_as_float(raw.z & 0xffff0000u);
+        r[6] = __uint_as_float(raw.w << 16); r[7] = __uint_as_float(raw.w & 0xffff0000u);
+    } else {
+        f16x8_t h;
+        __builtin_memcpy(&h, &raw, 16);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = (float)h[k];
+    }
+    return r;
+}
+
+__device__ __forceinline__ void apse_st8(void* base, size_t idx, const f32x8& v, int st) {
+    if (st == 0) {
+        apse_st4(base, idx, f32x4{v[0], v[1], v[2], v[3]}, 0);
+        apse_st4(base, idx + 4, f32x4{v[4], v[5], v[6], v[7]}, 0);
+    } else if (st == 1) {
+        bf16x8 b;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b[k] = (__bf16)v[k];
+        APSE_NT_STORE(b, reinterpret_cast<bf16x8*>(reinterpret_cast<uint16_t*>(base) + idx));
+    } else {
+        f16x8_t h;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] = (_Float16)v[k];
+        APSE_NT_STORE(h, reinterpret_cast<f16x8_t*>(reinterpret_cast<uint16_t*>(base) + idx));
+    }
+}
+
 __device__ __forceinline__ void apse_st1(void* base, size_t idx, float v, int st) {
     if (st == 0) reinterpret_cast<float*>(base)[idx] = v;
     else if (st == 1) reinterpret_cast<__bf16*>(base)[idx] = (__bf16)v;

@@ -29,6 +29,7 @@ int apse_k_pil_resize(const uint8_t*, uint8_t*, void*, int, uint8_t*, const int*
 int apse_k_undistort_build_map(const UndistortParams*, void*, float*, hipStream_t);
 int apse_k_chw_norm(const float*, void*, int, int, int, int, int, int, const float*, hipStream_t);
 int apse_k_maxpool3x3s2(const void*, void*, int, int, int, int, int, hipStream_t);
+int apse_k_stem_pool16(const void*, const uint16_t*, const float*, void*, int, int, int, int, hipStream_t, hipEvent_t, hipEvent_t);
 int apse_k_subsample2(const void*, void*, int, int, int, int, int, hipStream_t);
 int apse_k_nhwc_to_nchw(const void*, float*, int, int, int, int, hipStream_t);
 int apse_k_rpn_topk_stage(const RpnLevels*, const TopkJob*, int, uint64_t*, int, int, uint32_t*, hipStream_t);
@@ -73,6 +74,7 @@ struct ConvStep {
     int cfg = 0;
     double flops_per_item = 0;   // algorithmic 2*MACs per item (one image / one roi / one detection)
     int count_kind = 0;    // 0 none, 1 prop_cnt[0] (batch 1 only), 2 packed total
+    void* pool_y = nullptr;   // != nullptr: the stem of the 16-bit modes, run as stem_s2d_pool16 (conv + ReLU + 3x3/2 max-pool) into this map
     std::string name;
 };
 enum StepKind { S_CONV, S_MAXPOOL, S_SUBSAMPLE };
@@ -408,8 +410,14 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
                 c->ev_used = 2;
             }
             if (c->prof_on && c->ev_used + 2 <= (int)c->ev_pool.size()) { e0 = c->ev_used; c->ev_used += 2; }
-            rc = apse_launch_conv(p, cfg, s, e0 >= 0 ? c->ev_pool[e0] : nullptr, e0 >= 0 ? c->ev_pool[e0 + 1] : nullptr);
-            cfg = apse_conv_effective_cfg(p, cfg);                            // profile label of the kernel that actually ran
+            if (st.c.pool_y) {
+                rc = apse_k_stem_pool16(p.x, p.w16, p.bias, st.c.pool_y, batch, p.H, p.W, p.prec, s, e0 >= 0 ? c->ev_pool[e0] : nullptr,
+                                        e0 >= 0 ? c->ev_pool[e0 + 1] : nullptr);
+                cfg = APSE_CFG_STEMPOOL;
+            } else {
+                rc = apse_launch_conv(p, cfg, s, e0 >= 0 ? c->ev_pool[e0] : nullptr, e0 >= 0 ? c->ev_pool[e0 + 1] : nullptr);
+                cfg = apse_conv_effective_cfg(p, cfg);                        // profile label of the kernel that actually ran
+            }
             if (e0 >= 0) c->pending.push_back({cfg, st.c.flops_per_item, st.c.count_kind, st.c.b_mult, batch, e0, e0 + 1});
         } else if (st.kind == S_MAXPOOL) {
             rc = apse_k_maxpool3x3s2(st.x, st.y, batch, st.H, st.W, st.C, st.st, s);
@@ -451,6 +459,7 @@ static int build_plan(apse_ctx* c) {
     int rc;
     // ---- backbone
     Tens cur;
+    bool fused_stem = false;
     if (storage_type(c)) {
         // 16-bit storage modes: space-to-depth(2) input (elementwise.hip, input_store) and the stem as a 4x4 / stride-1 convolution
         // over 16 channels: one 64-element k-step per filter row on the scheduled 16-bit kernel (K = 256 instead of the 448 a
@@ -458,14 +467,28 @@ static int build_plan(apse_ctx* c) {
         Tens x0 = make_t(c, "input", B, c->PH / 2, c->PW / 2, 16, storage_type(c));
         ConvSpec sp{"stem.conv1", {"backbone.bottom_up.stem.conv1"}, 4, 4, 1, 2, 1};
         sp.s2d = 1;
-        rc = add_conv(c, c->backbone, sp, x0, 1, &cur, "stem.conv1", nullptr, 0, 0, 0);
+        // ... and the max-pool behind it in the same kernel (stem_pool16.hip): the stem output never goes to HBM.
+        // APSE_NO_STEM_FUSE (read when the context is built): the two-kernel form, for the equality test and A/B runs.
+        if (!getenv("APSE_NO_STEM_FUSE")) {
+            Tens pooled = make_t(c, "stem", B, (x0.H + 2 - 3) / 2 + 1, (x0.W + 2 - 3) / 2 + 1, 64, storage_type(c));
+            if (!pooled.p) return fail(c, APSE_E_NOMEM, "stem alloc");
+            Tens unused;
+            rc = add_conv(c, c->backbone, sp, x0, 1, &unused, "stem.conv1", nullptr, 0, 0, 0, nullptr, &pooled);
+            if (rc) return rc;
+            c->t.erase("stem.conv1");                       // no such tensor in this form
+            c->backbone.back().c.pool_y = pooled.p;
+            cur = pooled;
+            fused_stem = true;
+        } else {
+            rc = add_conv(c, c->backbone, sp, x0, 1, &cur, "stem.conv1", nullptr, 0, 0, 0);
+        }
     } else {
         Tens x0 = make_t(c, "input", B, c->PH, c->PW, 4);
         rc = add_conv(c, c->backbone, ConvSpec{"stem.conv1", {"backbone.bottom_up.stem.conv1"}, 7, 7, 2, 3, 1}, x0, 1, &cur,
                       "stem.conv1", nullptr, 0, 0, 0);
     }
     if (rc) return rc;
-    {
+    if (!fused_stem) {
         Step st; st.kind = S_MAXPOOL; st.x = cur.p; st.H = cur.H; st.W = cur.W; st.C = cur.C;
         Tens o = make_t(c, "stem", B, (cur.H + 2 - 3) / 2 + 1, (cur.W + 2 - 3) / 2 + 1, cur.C, cur.st);
         st.y = o.p; st.c.name = "stem.pool"; st.st = cur.st;
@@ -1004,9 +1027,9 @@ int apse_profile(apse_ctx* c, int enable) {
     return APSE_OK;
 }
 
-int apse_profile_read(apse_ctx* c, double* out36, int reset) {
-    if (!c || !out36) return APSE_E_INVALID;
-    memcpy(out36, c->prof, sizeof(c->prof));
+int apse_profile_read(apse_ctx* c, double* out39, int reset) {
+    if (!c || !out39) return APSE_E_INVALID;
+    memcpy(out39, c->prof, sizeof(c->prof));
     if (reset) memset(c->prof, 0, sizeof(c->prof));
     return APSE_OK;
 }
@@ -1186,6 +1209,11 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
 
 int apse_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream) {
     return apse_k_maxpool3x3s2(x, y, B, H, W, C, 0, (hipStream_t)stream);
+}
+
+int apse_maxpool3x3s2_typed(const void* x, void* y, int B, int H, int W, int C, int storage, void* stream) {
+    if (!x || !y || B < 1 || H < 1 || W < 1 || C < 4 || (C & 3) || storage < 0 || storage > 2) return APSE_E_INVALID;
+    return apse_k_maxpool3x3s2(x, y, B, H, W, C, storage, (hipStream_t)stream);
 }
 
 static int roi_align_stateless(const void* const* feats, const int* hs, const int* ws, const float* rois, int n, int per_img,

@@ -63,42 +63,6 @@ __device__ __forceinline__ RaAxis ra_axis(float s0, int pi, float bsz, int g, in
     return a;
 }
 
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ f32x8 ra_cvt8(const uint4 raw, int st) {       // 8 consecutive 16-bit channels -> f32
-    f32x8 r;
-    if (st == 1) {
-        r[0] = __uint_as_float(raw.x << 16); r[1] = __uint_as_float(raw.x & 0xffff0000u);
-        r[2] = __uint_as_float(raw.y << 16); r[3] = __uint_as_float(raw.y & 0xffff0000u);
-        r[4] = __uint_as_float(raw.z << 16); r[5] = __uint_as_float(raw.z & 0xffff0000u);
-        r[6] = __uint_as_float(raw.w << 16); r[7] = __uint_as_float(raw.w & 0xffff0000u);
-    } else {
-        f16x8_t h;
-        __builtin_memcpy(&h, &raw, 16);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] = (float)h[k];
-    }
-    return r;
-}
-
-__device__ __forceinline__ void ra_st8(void* base, size_t idx, const f32x8& v, int st) {
-    if (st == 0) {
-        apse_st4(base, idx, f32x4{v[0], v[1], v[2], v[3]}, 0);
-        apse_st4(base, idx + 4, f32x4{v[4], v[5], v[6], v[7]}, 0);
-    } else if (st == 1) {
-        bf16x8 b;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) b[k] = (__bf16)v[k];
-        APSE_NT_STORE(b, reinterpret_cast<bf16x8*>(reinterpret_cast<uint16_t*>(base) + idx));
-    } else {
-        f16x8_t h;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) h[k] = (_Float16)v[k];
-        APSE_NT_STORE(h, reinterpret_cast<f16x8_t*>(reinterpret_cast<uint16_t*>(base) + idx));
-    }
-}
-
 // the per-sample form (any window size); also the statement the separable form is derived from
 __device__ __forceinline__ f32x4 ra_bin_direct(const void* fmap, int st, size_t f, int H, int W, float sh, float sw, float bh,
                                                 float bw, int gh, int gw, int ph, int pw) {
@@ -242,14 +206,14 @@ __global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const flo
             }
 #pragma unroll
             for (int u = 0; u < RA_FLIGHT; ++u) {
-                const f32x8 v = ra_cvt8(raw[u], F.st);
+                const f32x8 v = apse_cvt8(raw[u], F.st);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] += w[u] * v[k];
             }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = (acc[k] + __shfl_xor(acc[k], 32)) / cntf;
-        if (half == 0) ra_st8(out, ((size_t)r * rr + pb) * 256 + cg * 8, acc, out_st);
+        if (half == 0) apse_st8(out, ((size_t)r * rr + pb) * 256 + cg * 8, acc, out_st);
     }
     }
     }

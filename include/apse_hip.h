@@ -156,12 +156,13 @@ int apse_debug_tensor(apse_ctx* ctx, const char* name, void* dst_dev, size_t max
 double apse_flops(apse_ctx* ctx, int batch, double proposals, double detections);
 
 /* Per-kernel timing with HIP events on the caller's stream (one pair per convolution launch, collected at
- * apse_read_results).  out36 = [12 kernel shapes][3] = {sum ms, sum algorithmic FLOPs, launches}; shapes
+ * apse_read_results).  out39 = [13 kernel shapes][3] = {sum ms, sum algorithmic FLOPs, launches}; shapes
  * 0..3 = 128x128, 64x64, 128x32, 128x64 implicit-GEMM tiles, 4..7 their 32-deep / 8-wave variants, 8 = 256x128,
  * 9 / 10 = the memory-streaming 1x1 kernels, A strip resident / streamed, 11 = the LDS-DMA
- * 256x128 kernel of the 16-bit modes (a split-K launch includes its reduce pass). */
+ * 256x128 kernel of the 16-bit modes, 12 = the fused stem + max-pool kernel of the 16-bit modes (a split-K launch
+ * includes its reduce pass). */
 int apse_profile(apse_ctx* ctx, int enable);
-int apse_profile_read(apse_ctx* ctx, double* out36, int reset);
+int apse_profile_read(apse_ctx* ctx, double* out39, int reset);
 
 /* ---- stage-level operators (stateless; used by the parity tests and by host-side helpers) ---- */
 typedef struct apse_conv_desc {
@@ -184,6 +185,8 @@ int apse_conv_pack_weight(const apse_conv_desc* d, const float* w_oihw, int cin_
 int apse_conv2d(const apse_conv_desc* d, const float* x_dev, const float* w_packed_dev, const float* bias_dev,
                 const float* res_dev, float* y_dev, float* ws_dev, size_t ws_bytes, void* stream);
 int apse_maxpool3x3s2(const float* x_dev, float* y_dev, int B, int H, int W, int C, void* stream);
+/* Same on a storage type (0 f32, 1 bf16, 2 f16): the form the 16-bit modes run after the stem. */
+int apse_maxpool3x3s2_typed(const void* x_dev, void* y_dev, int B, int H, int W, int C, int storage, void* stream);
 /* ROIAlignV2 over 4 levels (NHWC, C = 256); rois [n][4], batch index roi/per_img, all rois live. */
 int apse_roi_align(const float* const* feats_dev, const int* hs, const int* ws, const float* rois_dev, int n, int per_img,
                    int out_size, float* out_dev, void* stream);

@@ -347,6 +347,34 @@ def test_config3_like_batch4_bf16_with_preproc(setup, logdir, golden_dir):
     assert matched >= int(0.95 * tot)              # 16-bit noise floor flips a few near-threshold candidates
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("size", [(256, 448), (270, 480)], ids=["tiles_whole", "tiles_ragged"])
+def test_fused_stem_pool_equals_two_kernel_form(setup, dtype, size, monkeypatch):
+    """16-bit storage modes run the stem convolution + ReLU + max-pool as one kernel (csrc/stem_pool16.hip): the pooled map and
+    everything behind it must be the two-kernel form's bits (APSE_NO_STEM_FUSE, read when a context is built).
+    270x480 -> 72x120 pooled cells: the last tile column is half outside the map."""
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from hip_helpers import _live_bytes
+    frame = setup["seq"].frame(1)
+    got = []
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("APSE_NO_STEM_FUSE", "1")
+        else:
+            monkeypatch.delenv("APSE_NO_STEM_FUSE", raising=False)
+        cfg = _cfg()
+        cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = size
+        cfg.APSE.DTYPE = dtype
+        tr = RcnnTracker(cfg, FRAME, setup["asd"], detector_state=setup["sd"])
+        tr.predictor(frame)
+        model = tr.predictor.model
+        got.append((model.debug_tensor("stem").cpu(), model.debug_tensor("p2").cpu(), _live_bytes(model, model.last_results)))
+    assert got[0][0].shape == got[1][0].shape and got[0][0].numel() > 0
+    assert torch.equal(got[0][0].view(torch.int16), got[1][0].view(torch.int16))
+    assert torch.equal(got[0][1].view(torch.int16), got[1][1].view(torch.int16))
+    assert got[0][2] == got[1][2]
+
+
 def test_results_independent_of_history(setup, logdir):
     from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
     from hip_helpers import history_independence

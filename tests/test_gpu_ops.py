@@ -276,6 +276,20 @@ def test_maxpool(logdir):
     assert torch.equal(y.cpu().permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("st,dtype", [(1, torch.bfloat16), (2, torch.float16)])
+def test_maxpool_16bit(st, dtype):
+    """The 8-channels-per-thread form of the 16-bit modes: max is exact, so bit-equal to torch on the same 16-bit values."""
+    from apse_uav_amd import _lib
+    from hip_helpers import to_nhwc
+    x = torch.randn(2, 64, 37, 51).to(dtype)
+    ref = F.max_pool2d(x.float(), 3, 2, 1)
+    xd = to_nhwc(x.float()).to(dtype).cuda().contiguous()
+    y = torch.empty((2, ref.shape[2], ref.shape[3], 64), device="cuda", dtype=dtype)
+    assert _lib.load().apse_maxpool3x3s2_typed(_lib.ptr(xd), _lib.ptr(y), 2, 37, 51, 64, st, _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu().float().permute(0, 3, 1, 2), ref)
+
+
 @pytest.mark.parametrize("hw", [(2160, 3840), (540, 960), (333, 516)])
 def test_pil_resize_bit_exact(hw, logdir):
     """HIP two-pass integer resize + normalise vs Pillow itself (the reference's resampler)."""

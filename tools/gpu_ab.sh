@@ -24,7 +24,15 @@ both && both --batch 8 && both --dtype bf16 --batch 1 && both --dtype bf16 --bat
 [ -n "$libb" ] && { echo "ab done"; exit 0; }
 run --dtype bf16 --batch 4 --preproc || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --throughput-depth 0 --no-entrypoint --dtype f16 --batch 8 > /dev/null 2> $O/prof_$tag.err || exit 2
-cp $(find $O/prof_$tag -name "*kernel_stats.csv" | head -1) $O/${tag}_f16b8_stats.csv
-rm -rf $O/prof_$tag
+# kernel-stats passes (library A): GPU time per step is a steadier yardstick than frames/s
+for mode in "f16b8:--dtype f16 --batch 8" "bf16b1:--dtype bf16 --batch 1" "f32b1:"; do
+  name=${mode%%:*}; args=${mode#*:}
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --throughput-depth 0 --no-entrypoint $args > /dev/null 2> $O/prof_$tag.err || exit 2
+  cp $(find $O/prof_$tag -name "*kernel_stats.csv" | head -1) $O/${tag}_${name}_stats.csv
+  rm -rf $O/prof_$tag
+  python3 -c "
+import csv,sys
+rows=list(csv.DictReader(open('$O/${tag}_${name}_stats.csv')))
+print('KERNEL-TIME $name: %.1f us per step (14 steps)' % (sum(float(r['TotalDurationNs']) for r in rows)/1e3/14))" >> $O/${tag}_modes.txt
+done
 echo "ab done"
