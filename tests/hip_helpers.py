@@ -117,6 +117,15 @@ def _iou_matrix(a, b):
     return inter / (aa + ab - inter).clamp(min=1e-12)
 
 
+def _same_matrix(a, b):
+    """IoU, except that two boxes whose four coordinates all agree within 1 px count as the same box (1.0): candidates of one
+    stage are at least an anchor stride (4 px) apart, and the IoU of slivers -- proposals clipped to a fraction of a pixel at the
+    image border -- is sub-pixel noise (0.41 px against 0.71 px wide: IoU 0.57 with every coordinate within 0.3 px)."""
+    u = _iou_matrix(a, b)
+    d = (a.double()[:, None, :] - b.double()[None, :, :]).abs().amax(dim=2)
+    return torch.where(d <= 1.0, torch.ones_like(u), u)
+
+
 def hip_box_side(model, b=0):
     """Box-branch view of image ``b`` of the last forward: every (proposal, class) candidate and the kept detections,
     in resized-image pixels -- the HIP counterpart of the oracle's ``post["box_det"]``."""
@@ -172,7 +181,9 @@ def oracle_rpn_side(post):
 
 def explain_detection_sets(A, B, score_thr=0.5, nms_thr=0.5, match_iou=0.9):
     """Box-branch form of ``explain_sets`` (sides from hip_box_side / oracle_box_side)."""
-    return explain_sets(_flat_box_side(A), _flat_box_side(B), score_thr, nms_thr, match_iou=match_iou, noise_floor=0.3)
+    # noise sample: every candidate pair with p > 0.02 (scores are compared as logits, where the noise does not depend on p: the
+    # floor only drops the thousands of background-certain candidates, whose probabilities sit at the clamp)
+    return explain_sets(_flat_box_side(A), _flat_box_side(B), score_thr, nms_thr, match_iou=match_iou, noise_floor=0.02)
 
 
 def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise_floor=None, pre_topk=None):
@@ -194,10 +205,22 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
               keeps the better-scored of an overlapping pair) with both score changes within eps_score, or
       (top-k) the other run does not even rank it: its category's candidate list is full (``pre_topk``) and ends within
               eps_score of this item's score (the per-level pre-NMS cut of the RPN).
+    Scores are compared in the space the noise is uniform in: the RPN's objectness values are logits already; the box branch's
+    are softmax probabilities, whose response to the same logit noise is p (1 - p) -- 0.25 at the 0.5 threshold, 0.09 at 0.9 --
+    so they are compared as log(p / (1 - p)) (``score_thr`` given).  Items are paired with ``_same_matrix``.
     "Within eps" means within BAND x the largest deviation seen on the other candidates (BAND = 1.5: the disputed item is
     one more draw from the same noise, and the maximum of ~10^2 draws is exceeded by a fresh one about once in 10^2).
     Everything else -- including "the other run has no such candidate" -- is returned in ``unexplained``."""
     BAND = 1.5
+    if score_thr is not None:
+        def sp(v):
+            return torch.logit(torch.as_tensor(v, dtype=torch.double).clamp(1e-7, 1 - 1e-7))
+    else:
+        def sp(v):
+            return torch.as_tensor(v, dtype=torch.double)
+
+    def spf(v):
+        return float(sp(v))
     rep = dict(nA=int(A["boxes"].shape[0]), nB=int(B["boxes"].shape[0]))
     fa = A["cand_scores"] > noise_floor if noise_floor is not None else torch.ones_like(A["cand_scores"], dtype=torch.bool)
     ca = (A["cand_boxes"][fa], A["cand_scores"][fa], A["cand_cat"][fa])
@@ -221,14 +244,14 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
                 continue
             for lo in range(0, ia_.numel(), 1024):
                 blk = ia_[lo:lo + 1024]
-                m, a = _iou_matrix(ca[0][blk], cb[0][ib_]).max(dim=1)
+                m, a = _same_matrix(ca[0][blk], cb[0][ib_]).max(dim=1)
                 best[blk], arg[blk] = m, ib_[a]
         ok = best >= match_iou
         n_pairs = int(ok.sum())
         if n_pairs:
             ia = ok.nonzero()[:, 0]
             ib = arg[ia]
-            pair_box, pair_ds = ca[0][ia], (ca[1][ia] - cb[1][ib]).abs()
+            pair_box, pair_ds = ca[0][ia], (sp(ca[1][ia]) - sp(cb[1][ib])).abs()
             eps_s = float(pair_ds.max())
             eps_box = float((ca[0][ia] - cb[0][ib]).abs().max())
             ia, ib = ia[:400], ib[:400]
@@ -238,7 +261,9 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
             du = (ua - ub).abs() * band
             if int(band.sum()):
                 eps_iou = float(du.max())
-    rep.update(cand_pairs=n_pairs, eps_score=eps_s, eps_box_px=eps_box, eps_iou=eps_iou)
+    rep.update(cand_pairs=n_pairs, eps_score=eps_s, eps_box_px=eps_box, eps_iou=eps_iou,
+               score_noise_largest=[round(float(v), 5) for v in torch.sort(pair_ds, descending=True).values[:8]],
+               score_space="logit of the probability" if score_thr is not None else "as given (logits)")
     # pair the kept items
     pairs, onlyA, onlyB = [], [], list(range(rep["nB"]))
     if rep["nA"] and rep["nB"]:
@@ -246,7 +271,7 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
             sel = (B["cats"] == A["cats"][i]).nonzero()[:, 0]
             j = -1
             if sel.numel():
-                u = _iou_matrix(A["boxes"][i][None], B["boxes"][sel])[0]
+                u = _same_matrix(A["boxes"][i][None], B["boxes"][sel])[0]
                 for k in torch.argsort(u, descending=True).tolist():
                     if float(u[k]) < match_iou:
                         break
@@ -271,13 +296,13 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
         item = dict(side=who, index=i, score=s, cat=cat, box=[round(float(v), 2) for v in box])
         yb, ys, yc = Y["cand_boxes"], Y["cand_scores"], Y["cand_cat"]
         sel = (yc == cat).nonzero()[:, 0]
-        uu = _iou_matrix(box[None], yb[sel])[0] if sel.numel() else torch.zeros(0, dtype=torch.double)
+        uu = _same_matrix(box[None], yb[sel])[0] if sel.numel() else torch.zeros(0, dtype=torch.double)
         far = _iou_matrix(box[None], pair_box)[0] < 0.5 if pair_box.shape[0] else torch.zeros(0, dtype=torch.bool)
         eps_here = float(pair_ds[far].max()) if int(far.sum()) else 0.0       # score noise of the other candidates
         if sel.numel() and float(uu.max()) < match_iou:
             # noisy runs (bf16 moves small boxes by several pixels): the same candidate may fall below match_iou.  Accept one
             # that still overlaps by >= 0.7 AND carries the same score within the measured score noise
-            near = (uu >= 0.7) & ((ys[sel] - s).abs() <= max(BAND * eps_here, 1e-6))
+            near = (uu >= 0.7) & ((sp(ys[sel]) - spf(s)).abs() <= max(BAND * eps_here, 1e-6))
             if bool(near.any()):
                 k2 = int(torch.where(near, uu, torch.zeros_like(uu)).argmax())
                 c2 = sel[k2]
@@ -293,16 +318,17 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
                 cut = float(ys[sel].min())                       # the other run's list of this category is full and ends here
                 item.update(why="pre-NMS top-k cut", other_cut_score=cut, margin_to_cut=round(s - cut, 6),
                             eps_score_of_the_others=round(eps_here, 6))
-                return item, (s - cut) <= max(BAND * eps_here, 1e-6)
+                return item, (spf(s) - spf(cut)) <= max(BAND * eps_here, 1e-6)
             return item, False
         c = sel[int(uu.argmax())]
         sy = float(ys[c])
-        item.update(other_score=sy, score_diff=round(abs(s - sy), 6), eps_score_of_the_others=round(eps_here, 6))
+        dsy = abs(spf(s) - spf(sy))                          # in the comparison space (logits)
+        item.update(other_score=sy, score_diff=round(dsy, 6), eps_score_of_the_others=round(eps_here, 6))
         if score_thr is not None:
             item.update(score_margin_to_thr=round(s - score_thr, 6), other_margin_to_thr=round(sy - score_thr, 6))
             if sy <= score_thr:
                 item["why"] = "score threshold"
-                return item, abs(s - sy) <= max(BAND * eps_here, 1e-6)
+                return item, dsy <= max(BAND * eps_here, 1e-6)
         # a live candidate in Y that Y does not keep: suppressed by a BETTER-scored kept item of its category (greedy NMS), or
         # past the rank cut
         ksel = ((Y["cats"] == cat) & (Y["scores"] >= sy)).nonzero()[:, 0]
@@ -327,12 +353,12 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
                 # (near-tied scores: greedy NMS keeps whichever ranks first) ...
                 qb = Y["boxes"][j]
                 xsel = (X["cand_cat"] == cat).nonzero()[:, 0]
-                uq = _iou_matrix(qb[None], X["cand_boxes"][xsel])[0] if xsel.numel() else torch.zeros(0, dtype=torch.double)
+                uq = _same_matrix(qb[None], X["cand_boxes"][xsel])[0] if xsel.numel() else torch.zeros(0, dtype=torch.double)
                 if xsel.numel() and float(uq.max()) >= match_iou:
                     sq_x = float(X["cand_scores"][xsel[int(uq.argmax())]])
                     sq_y = float(Y["scores"][j])
                     item.update(q_score_here=sq_x, q_score_other=sq_y)
-                    if sq_x <= s and sq_y >= sy and abs(s - sy) <= max(BAND * eps_here, 1e-6) and abs(sq_x - sq_y) <= max(BAND * eps_here, 1e-6):
+                    if sq_x <= s and sq_y >= sy and dsy <= max(BAND * eps_here, 1e-6) and abs(spf(sq_x) - spf(sq_y)) <= max(BAND * eps_here, 1e-6):
                         item["why"] = "order swap: the runs rank this item and its overlapping rival differently, both score changes inside the noise"
                         return item, True
                 # ... or q's presence there is a disagreement of its own: resolved below once every direct case is known
@@ -347,7 +373,7 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
         if rank_limit is not None and Y["boxes"].shape[0] >= rank_limit:
             last = float(Y["scores"].min())
             item.update(why="rank cut", other_last_kept_score=last, margin_to_last=round(sy - last, 6))
-            return item, (sy <= last + 1e-12 or abs(sy - last) <= max(BAND * eps_here, 1e-6)) and abs(s - sy) <= max(BAND * eps_here, 1e-6)
+            return item, (sy <= last + 1e-12 or abs(spf(sy) - spf(last)) <= max(BAND * eps_here, 1e-6)) and dsy <= max(BAND * eps_here, 1e-6)
         item["why"] = "live in the other run, not kept, no suppressor found"
         return item, False
 

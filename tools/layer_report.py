@@ -58,9 +58,11 @@ items = []
 for r in fr:
     kn = r['Kernel_Name']
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    if any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16')):
+    if any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'stem_s2d_pool16')):
         # the __bf16 template argument defeats rocprofv3's demangler: fall back to the raw name
-        if 'conv1x1_stream' in kn:
+        if 'stem_s2d_pool16' in kn:
+            lab = 'stem+pool fused'
+        elif 'conv1x1_stream' in kn:
             lab = 'stream' + (kn.split('<')[1].split('>')[0] if '<' in kn else '')
         elif 'conv_glds16' in kn:
             lab = 'glds' + (kn.split('<')[1].split('>')[0] if '<' in kn else '')
@@ -84,7 +86,7 @@ for k, (d, fl, n) in agg.items():
 others = collections.Counter()
 for r in fr:
     kn = r['Kernel_Name']
-    if not any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'conv_splitk_reduce')):
+    if not any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'conv_splitk_reduce', 'stem_s2d_pool16')):
         others[kn.split('(')[0].replace('void ', '')[:40]] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 print('non-conv kernels:')
 for k, v in others.most_common(14):
