@@ -58,6 +58,8 @@ class FrameUploader:
     arrays) into the next slot's pinned buffer and enqueues the H2D on ``stream``; the slot's device buffer is
     overwritten only after its previous consumer has run (``consumed`` event, recorded by ``release``)."""
 
+    BANDS = 4
+
     def __init__(self, device, input_format="BGR", nslots=2):
         self.device = torch.device(device)
         self.input_format = input_format
@@ -75,18 +77,25 @@ class FrameUploader:
             sl = self._slots[self._k] = _Slot(shape, self.device)
         else:
             sl.h2d_done.synchronize()                 # the pinned buffer's previous H2D has left the host
-        for i, f in enumerate(frames):
+        for f in frames:
             if f.shape[:2] != (H, W):
                 raise ValueError("frames of one batch must have the same size")
-            if self.input_format == "RGB":            # track_predictor.py:43-45: the model wants BGR
-                f = f[:, :, ::-1]
-            _host_copy(sl.pinned_np[i], f)            # strided source (the RGB flip) is handled by numpy
         if sl.consumed_pending:                       # a caller that never released the slot: be conservative
             sl.consumed.record(torch.cuda.current_stream(self.device))
             sl.consumed_pending = False
         with torch.cuda.stream(stream):
             stream.wait_event(sl.consumed)            # device buffer: its last reader (the resize kernels) is done
-            sl.dev.copy_(sl.pinned, non_blocking=True)
+            # staged and sent in row bands: while band k crosses PCIe, the host threads copy band k + 1 into the pinned buffer
+            # (a 4K frame: ~1 ms of host copy + ~0.5 ms of DMA, overlapped instead of back to back)
+            nb = self.BANDS if H >= 8 * self.BANDS else 1
+            step = (H + nb - 1) // nb
+            for i, f in enumerate(frames):
+                if self.input_format == "RGB":        # track_predictor.py:43-45: the model wants BGR
+                    f = f[:, :, ::-1]
+                for lo in range(0, H, step):
+                    hi = min(lo + step, H)
+                    _host_copy(sl.pinned_np[i, lo:hi], f[lo:hi])      # strided source (the RGB flip) is handled by numpy
+                    sl.dev[i, lo:hi].copy_(sl.pinned[i, lo:hi], non_blocking=True)
             sl.h2d_done.record(stream)
         sl.key = list(frames)                        # references, so identity stays meaningful until the slot is reused
         sl.consumed_pending = True
