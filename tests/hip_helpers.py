@@ -244,7 +244,7 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
                 continue
             for lo in range(0, ia_.numel(), 1024):
                 blk = ia_[lo:lo + 1024]
-                m, a = _same_matrix(ca[0][blk], cb[0][ib_]).max(dim=1)
+                m, a = _iou_matrix(ca[0][blk], cb[0][ib_]).max(dim=1)        # noise sample: plain IoU (slivers clipped at the border coincide within 1 px although they are different anchors)
                 best[blk], arg[blk] = m, ib_[a]
         ok = best >= match_iou
         n_pairs = int(ok.sum())
