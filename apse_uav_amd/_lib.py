@@ -87,7 +87,7 @@ def load():
         "apse_debug_tensor": ([vp, C.c_char_p, vp, sz, C.POINTER(sz), vp], i),
         "apse_flops": ([vp, i, C.c_double, C.c_double], C.c_double),
         "apse_profile": ([vp, i], i),
-        "apse_profile_read": ([vp, C.POINTER(C.c_double * 39), i], i),
+        "apse_profile_read": ([vp, C.POINTER(C.c_double * 42), i], i),
         "apse_conv_packed_elems": ([C.POINTER(ConvDesc)], sz),
         "apse_conv_pack_weight": ([C.POINTER(ConvDesc), vp, i, vp, vp], i),
         "apse_conv2d": ([C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, sz, vp], i),

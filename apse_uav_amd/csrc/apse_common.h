@@ -60,12 +60,15 @@ int apse_launch_conv_bf16(const ConvParams& p, int cfg, hipStream_t s);   // con
 #define APSE_CFG_STREAM_K 10
 #define APSE_CFG_GLDS 11             // conv_glds16.hip: 256x128 tile, 16-bit operands, LDS-DMA ring
 #define APSE_CFG_STEMPOOL 12         // stem_pool16.hip: stem convolution + ReLU + max-pool of the 16-bit modes (profile label only)
-#define APSE_NCFG 13
+#define APSE_CFG_SKINNY 13           // conv_skinny.hip: <= 16 output channels over K = 256, activations straight into 16x16x4 MFMAs (RPN head, mask predictor)
+#define APSE_NCFG 14
 bool apse_conv1x1_stream_ok(const ConvParams& p);
 int apse_launch_conv1x1_stream(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 bool apse_conv1x1_stream_k_ok(const ConvParams& p);
 int apse_launch_conv1x1_stream_k(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 bool apse_conv_glds16_ok(const ConvParams& p);
+bool apse_conv_skinny_ok(const ConvParams& p);
+int apse_launch_conv_skinny(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int apse_launch_conv_glds16(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // which kernel apse_launch_conv runs for (p, cfg): APSE_CFG_STREAM / APSE_CFG_STREAM_K, or cfg itself (a tiled shape)
 int apse_conv_effective_cfg(const ConvParams& p, int cfg);

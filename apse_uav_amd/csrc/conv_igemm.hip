@@ -686,6 +686,8 @@ int apse_conv_effective_cfg(const ConvParams& p, int cfg) {
     if (cfg == APSE_CFG_STREAM) return (!p.no_stream && apse_conv1x1_stream_ok(p)) ? APSE_CFG_STREAM : -1;
     if (cfg == APSE_CFG_STREAM_K) return (!p.no_stream && apse_conv1x1_stream_k_ok(p)) ? APSE_CFG_STREAM_K : -1;
     if (cfg == APSE_CFG_GLDS) return apse_conv_glds16_ok(p) ? APSE_CFG_GLDS : -1;
+    if (cfg == APSE_CFG_SKINNY) return apse_conv_skinny_ok(p) ? APSE_CFG_SKINNY : -1;
+    if (!p.no_stream && apse_conv_skinny_ok(p)) return APSE_CFG_SKINNY;
     if (!p.no_stream) {
         if (apse_conv1x1_stream_ok(p)) return APSE_CFG_STREAM;
         if (p.stream_k && apse_conv1x1_stream_k_ok(p)) return APSE_CFG_STREAM_K;
@@ -703,6 +705,7 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0
     if (eff == APSE_CFG_STREAM) return apse_launch_conv1x1_stream(p, s, ev0, ev1);
     if (eff == APSE_CFG_STREAM_K) return apse_launch_conv1x1_stream_k(p, s, ev0, ev1);
     if (eff == APSE_CFG_GLDS) return apse_launch_conv_glds16(p, s, ev0, ev1);
+    if (eff == APSE_CFG_SKINNY) return apse_launch_conv_skinny(p, s, ev0, ev1);
     if (p.prec == 1 || p.prec == 2) {
         const int c16 = fast16_shape(p, cfg);
         if (c16 >= 0) {
@@ -767,7 +770,18 @@ int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk) {
         if (sk > 64) sk = 64;
         return sk < 1 ? 1 : sk;
     };
-    if (Cout <= 32) return 2;
+    if (Cout <= 32) {
+        // narrow heads over few rows (box predictor: 1000 rows x K = 1024 is 8 tiles of 128 rows): split K so that the launch
+        // has ~64 blocks instead of one long k loop on 8 CUs (28.7 -> ~14 us incl. the reduce pass)
+        const int t = tiles(128, 32);
+        if (t < 32 && steps >= 16) {
+            int sk = 64 / t;
+            if (sk > steps / 4) sk = steps / 4;
+            if (sk > 8) sk = 8;
+            *splitk = sk < 1 ? 1 : sk;
+        }
+        return 2;
+    }
     if (Cout <= 64) return tiles(128, 64) >= 192 ? 3 : 1;
     const int t128 = tiles(128, 128);
     if (t128 >= 224) {

@@ -1027,9 +1027,9 @@ int apse_profile(apse_ctx* c, int enable) {
     return APSE_OK;
 }
 
-int apse_profile_read(apse_ctx* c, double* out39, int reset) {
-    if (!c || !out39) return APSE_E_INVALID;
-    memcpy(out39, c->prof, sizeof(c->prof));
+int apse_profile_read(apse_ctx* c, double* out42, int reset) {
+    if (!c || !out42) return APSE_E_INVALID;
+    memcpy(out42, c->prof, sizeof(c->prof));
     if (reset) memset(c->prof, 0, sizeof(c->prof));
     return APSE_OK;
 }
@@ -1177,7 +1177,7 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
     if (p.x_st && cin_p < 8) return APSE_E_INVALID;
     int sk = 1;
     int cfg = apse_conv_pick_cfg(p.M, p.Cout, p.steps_total, &sk);
-    if (d->cfg >= 0) { cfg = d->cfg; sk = 1; p.no_stream = (d->cfg != APSE_CFG_STREAM && d->cfg != APSE_CFG_STREAM_K && d->cfg != APSE_CFG_GLDS); }
+    if (d->cfg >= 0) { cfg = d->cfg; sk = 1; p.no_stream = (d->cfg != APSE_CFG_STREAM && d->cfg != APSE_CFG_STREAM_K && d->cfg != APSE_CFG_GLDS && d->cfg != APSE_CFG_SKINNY); }
     if (d->splitk > 0) sk = d->splitk;
     if (sk > p.steps_total) sk = p.steps_total;
     p.splitk = sk;

@@ -27,11 +27,11 @@ sys.path.insert(0, ROOT)
 
 CFG_NAMES = ["conv_igemm<128x128>", "conv_igemm<64x64>", "conv_igemm<128x32>", "conv_igemm<128x64>",
              "conv_igemm<64x64,k32>", "conv_igemm<128x32,k32>", "conv_igemm<64x64,8 waves,k64>", "conv_igemm<64x64,8 waves,k128>",
-             "conv_igemm<256x128>", "conv1x1_stream", "conv1x1_stream_k", "conv_glds16<256x128>", "stem_s2d_pool16"]
+             "conv_igemm<256x128>", "conv1x1_stream", "conv1x1_stream_k", "conv_glds16<256x128>", "stem_s2d_pool16", "conv_skinny16"]
 # template arguments <WM, WN, TM, TN, KS, XT, WK, PR> of conv_igemm_f32 behind each tile shape (f32 path, f32 activations):
 # the kernel names rocprofv3 reports, used to look the dominant kernel up in the committed PMC summary
 CFG_TEMPLATE = ["<2, 2, 2, 2, 1, 0, 1, 0>", "<2, 2, 1, 1, 2, 0, 1, 0>", "<4, 1, 1, 1, 2, 0, 1, 0>", "<4, 1, 1, 2, 1, 0, 1, 0>",
-                "<2, 2, 1, 1, 1, 0, 1, 0>", "<4, 1, 1, 1, 1, 0, 1, 0>", "<2, 2, 1, 1, 2, 0, 2, 0>", "<2, 2, 1, 1, 4, 0, 2, 0>", None, None, None, None, None]
+                "<2, 2, 1, 1, 1, 0, 1, 0>", "<4, 1, 1, 1, 1, 0, 1, 0>", "<2, 2, 1, 1, 2, 0, 2, 0>", "<2, 2, 1, 1, 4, 0, 2, 0>", None, None, None, None, None, None]
 NCFG = len(CFG_NAMES)
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_latest.json")
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense

@@ -156,13 +156,13 @@ int apse_debug_tensor(apse_ctx* ctx, const char* name, void* dst_dev, size_t max
 double apse_flops(apse_ctx* ctx, int batch, double proposals, double detections);
 
 /* Per-kernel timing with HIP events on the caller's stream (one pair per convolution launch, collected at
- * apse_read_results).  out39 = [13 kernel shapes][3] = {sum ms, sum algorithmic FLOPs, launches}; shapes
+ * apse_read_results).  out42 = [14 kernel shapes][3] = {sum ms, sum algorithmic FLOPs, launches}; shapes
  * 0..3 = 128x128, 64x64, 128x32, 128x64 implicit-GEMM tiles, 4..7 their 32-deep / 8-wave variants, 8 = 256x128,
  * 9 / 10 = the memory-streaming 1x1 kernels, A strip resident / streamed, 11 = the LDS-DMA
- * 256x128 kernel of the 16-bit modes, 12 = the fused stem + max-pool kernel of the 16-bit modes (a split-K launch
- * includes its reduce pass). */
+ * 256x128 kernel of the 16-bit modes, 12 = the fused stem + max-pool kernel of the 16-bit modes, 13 = the <= 16-channel
+ * head kernel (a split-K launch includes its reduce pass). */
 int apse_profile(apse_ctx* ctx, int enable);
-int apse_profile_read(apse_ctx* ctx, double* out39, int reset);
+int apse_profile_read(apse_ctx* ctx, double* out42, int reset);
 
 /* ---- stage-level operators (stateless; used by the parity tests and by host-side helpers) ---- */
 typedef struct apse_conv_desc {

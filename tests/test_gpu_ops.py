@@ -249,6 +249,52 @@ def test_conv1x1_stream(case, prec, logdir):
         assert same > 0.98                      # same chain up to the order of the bias / residual adds
 
 
+SKINNY_CASES = [
+    # name, B, H, W, Cout, relu      -- conv_skinny16 (csrc/conv_skinny.hip, cfg 13): 1x1 over 256 channels, <= 16 outputs
+    ("sk16_rpn_head", 1, 37, 53, 15, False),          # 3 objectness + 12 deltas; M = 1961: ragged last group of tiles
+    ("sk16_mask_logits", 3, 28, 28, 4, False),        # 4 class logits per mask pixel
+    ("sk16_full16_relu", 2, 16, 24, 16, True),
+    ("sk16_tiny", 1, 3, 5, 1, False),                 # fewer rows than one tile
+]
+
+
+@pytest.mark.parametrize("xst", [0, 1, 2], ids=["x_f32", "x_bf16", "x_f16"])
+@pytest.mark.parametrize("case", SKINNY_CASES, ids=[c[0] for c in SKINNY_CASES])
+def test_conv_skinny16(case, xst, logdir):
+    """f32 filters, exact f32 MFMA in every mode; x stored as f32 / bf16 / f16.  Against torch CPU f32 on the same (rounded) x."""
+    from hip_helpers import hip_conv2d, err_stats
+    import zlib
+    name, B, H, W, Cout, relu = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    dt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[xst]
+    x = torch.randn(B, 256, H, W, generator=g).to(dt).to(torch.float32)
+    w = torch.randn(Cout, 256, 1, 1, generator=g) / 16.0
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b)
+    if relu:
+        ref = F.relu(ref)
+    out = hip_conv2d(x, w, b, 1, 0, relu, None, 0, 13, 0, prec=0, x_st=xst, res_st=0, y_st=0)
+    tiled = hip_conv2d(x, w, b, 1, 0, relu, None, 0, 2, 0, prec=0, x_st=xst, res_st=0, y_st=0)
+    st = err_stats(out, ref)
+    _log(logdir, "conv_skinny/%d/" % xst + name, dict(st, vs_tiled=err_stats(out, tiled)["rel_to_max"]))
+    assert st["nan"] == 0 and st["rel_to_max"] < 2e-5, st
+    assert torch.equal(out, hip_conv2d(x, w, b, 1, 0, relu, None, 0, 13, 0, prec=0, x_st=xst, res_st=0, y_st=0))
+
+
+def test_conv_skinny16_refuses_ineligible_layers():
+    from apse_uav_amd import _lib
+    lib = _lib.load()
+    for (cin, cout, k) in ((256, 32, 1), (128, 8, 1), (256, 8, 3)):
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad = 1, 8, 8, cin, cout, k, k, 1, k // 2
+        d.cfg = 13
+        x = torch.zeros(1, 8, 8, cin, device="cuda")
+        wp = torch.zeros(lib.apse_conv_packed_elems(C.byref(d)), device="cuda")
+        y = torch.zeros(1, 8, 8, cout, device="cuda")
+        ws = torch.zeros(16, device="cuda")
+        assert lib.apse_conv2d(C.byref(d), _lib.ptr(x), _lib.ptr(wp), None, None, _lib.ptr(y), _lib.ptr(ws), 64, _lib.stream_ptr()) != 0
+
+
 def test_conv1x1_stream_refuses_ineligible_layers():
     """cfg 9 on a layer the streaming kernel does not take (3x3, K = 512, narrow N) is an error, never a silent fallback."""
     from apse_uav_amd import _lib
