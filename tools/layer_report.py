@@ -58,10 +58,12 @@ items = []
 for r in fr:
     kn = r['Kernel_Name']
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    if any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'stem_s2d_pool16')):
+    if any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'stem_s2d_pool16', 'conv_skinny16')):
         # the __bf16 template argument defeats rocprofv3's demangler: fall back to the raw name
         if 'stem_s2d_pool16' in kn:
             lab = 'stem+pool fused'
+        elif 'conv_skinny16' in kn:
+            lab = 'skinny' + (kn.split('<')[1].split('>')[0] if '<' in kn else '')
         elif 'conv1x1_stream' in kn:
             lab = 'stream' + (kn.split('<')[1].split('>')[0] if '<' in kn else '')
         elif 'conv_glds16' in kn:
@@ -86,7 +88,7 @@ for k, (d, fl, n) in agg.items():
 others = collections.Counter()
 for r in fr:
     kn = r['Kernel_Name']
-    if not any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'conv_splitk_reduce', 'stem_s2d_pool16')):
+    if not any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'conv_splitk_reduce', 'stem_s2d_pool16', 'conv_skinny16')):
         others[kn.split('(')[0].replace('void ', '')[:40]] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 print('non-conv kernels:')
 for k, v in others.most_common(14):
