@@ -229,6 +229,10 @@ def main():
     for i in range(args.warmup):
         res = step(i, False)
     torch.cuda.synchronize()
+    if dist is not None:
+        # warm-up of the exchange step too: the first collective of a size creates RCCL channels / buffers (hundreds of ms), which is
+        # start-up cost like the context build, not part of a frame
+        gather_records([], rank, world, coll_dev, unpack=False)
     lib.apse_profile(model._ctx, 0)
     if dist is not None:
         dist.barrier()
@@ -387,12 +391,14 @@ def rehearse_spawn(args, rank, world, backend):
         dist.destroy_process_group()
 
 
-def throughput_mode(cfg, sd, tracker, model, frames, nres, B, depth, replay, steps=24, warmup=4):
-    warmup = max(warmup, depth + 1)          # every slot's context is built (first forward) before the timed part
+def throughput_mode(cfg, sd, tracker, model, frames, nres, B, depth, replay, steps=96, warmup=4):
     """Same frames, same per-frame results, `depth` frames in flight on separate streams / contexts
     (apse_uav_amd.engines.pipelined_tracker.PipelinedRcnnTracker: detector per frame on its own stream, association
     on the host in frame order): the small-grid layers of one frame (res4/res5 at batch 1 fill ~1 block per CU)
-    overlap with other frames'.  Informational: the headline value is the single-stream run above."""
+    overlap with other frames'.  Informational: the headline value is the single-stream run above.
+    The timed part starts and ends with an EMPTY pipeline (fill and drain included): 96 frames keep that to a few per cent
+    (24 frames at depth 4 read 175 where a long run reads 190+)."""
+    warmup = max(warmup, depth + 1)          # every slot's context is built (first forward) before the timed part
     from apse_uav_amd.engines.pipelined_tracker import PipelinedRcnnTracker
     if B != 1:
         return None
