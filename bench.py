@@ -396,8 +396,7 @@ def throughput_mode(cfg, sd, tracker, model, frames, nres, B, depth, replay, ste
     (apse_uav_amd.engines.pipelined_tracker.PipelinedRcnnTracker: detector per frame on its own stream, association
     on the host in frame order): the small-grid layers of one frame (res4/res5 at batch 1 fill ~1 block per CU)
     overlap with other frames'.  Informational: the headline value is the single-stream run above.
-    The timed part starts and ends with an EMPTY pipeline (fill and drain included): 96 frames keep that to a few per cent
-    (24 frames at depth 4 read 175 where a long run reads 190+)."""
+    The timed part starts and ends with an EMPTY pipeline (fill and drain included); 96 frames keep that share small."""
     warmup = max(warmup, depth + 1)          # every slot's context is built (first forward) before the timed part
     from apse_uav_amd.engines.pipelined_tracker import PipelinedRcnnTracker
     if B != 1:
