@@ -29,6 +29,8 @@ int apse_k_pil_resize(const uint8_t*, uint8_t*, void*, int, uint8_t*, const int*
 int apse_k_undistort_build_map(const UndistortParams*, void*, float*, hipStream_t);
 int apse_k_chw_norm(const float*, void*, int, int, int, int, int, int, const float*, hipStream_t);
 int apse_k_maxpool3x3s2(const void*, void*, int, int, int, int, int, hipStream_t);
+bool apse_assoc_fc_ok(int K, int N);
+int apse_k_assoc_fc(const float*, const float*, const float*, float*, const int*, int, int, int, float*, float*, hipStream_t);
 int apse_k_stem_pool16(const void*, const uint16_t*, const float*, void*, int, int, int, int, hipStream_t, hipEvent_t, hipEvent_t);
 int apse_k_subsample2(const void*, void*, int, int, int, int, int, hipStream_t);
 int apse_k_nhwc_to_nchw(const void*, float*, int, int, int, int, hipStream_t);
@@ -108,6 +110,7 @@ struct apse_ctx {
     // mask tail
     uint64_t* bits = nullptr; unsigned long long* sums = nullptr; unsigned long long* cp_keys = nullptr; int wpr = 0;
     float* emb_raw = nullptr;
+    float* ws_assoc = nullptr;      // [K / 128][max detections][embed_dim]: K slices of the association FC (apse_k_assoc_fc), or nullptr
     float* rf_mask = nullptr; size_t rf_mask_floats = 0;      // apse_roi_features: masks at p2 resolution (grown on demand)
     bool box_maxc_clean = false;
     UndistortParams cam; bool cam_on = false; uint8_t* cam_lut = nullptr; void* cam_map = nullptr; float* cam_lin = nullptr;     // apse_set_camera: fused undistort + gamma in apse_preprocess_frames
@@ -723,6 +726,13 @@ static int build_plan(apse_ctx* c) {
         c->emb_raw = dalloc<float>(c, (size_t)NM * g.embed_dim);
         rc = add_conv(c, c->embedfc, sp, ap, KD, &er, "assoc_fc", nullptr, 0, 0, 2, c->emb_raw);
         if (rc) return rc;
+        const ConvParams& fp = c->embedfc[0].c.p;
+        // the same filters through the K-sliced form when the shape allows (K = 25600, N = 128 in the reference); APSE_NO_ASSOC_FC
+        // (read when the context is built) keeps the split-K convolution + normalise kernels
+        if (fp.w && fp.KWCp == R * 256 && apse_assoc_fc_ok(fp.KH * fp.KWCp, g.embed_dim) && !getenv("APSE_NO_ASSOC_FC")) {
+            c->ws_assoc = dalloc<float>(c, (size_t)(fp.KH * fp.KWCp / 128) * NM * g.embed_dim, false);
+            if (!c->ws_assoc) return fail(c, APSE_E_NOMEM, "association FC workspace");
+        }
     }
     if (c->ws_floats) {
         c->ws = dalloc<float>(c, c->ws_floats, false);
@@ -967,6 +977,13 @@ int apse_embed(apse_ctx* c, int batch, void* stream) {
     int rc = apse_k_roi_pool(p2.p, p2.st, p2.H, p2.W, (float*)(r + c->lay.box), (int*)(r + c->lay.img), total, NM, g.assoc_roi,
                              g.assoc_scale, (float*)c->t["assoc_pooled"].p, 0, 0, s);
     if (rc) return fail(c, rc, "roi_pool launch failed");
+    if (c->ws_assoc) {
+        // K-sliced FC + ordered reduction + normalise (roi.hip): the filters of the plan's convolution step, its own two kernels
+        const ConvParams& fp = c->embedfc[0].c.p;
+        rc = apse_k_assoc_fc((const float*)c->t["assoc_pooled"].p, fp.w, fp.bias, c->ws_assoc, total, NM, fp.KH * fp.KWCp, g.embed_dim,
+                             c->emb_raw, (float*)(r + c->lay.embedding), s);
+        return rc ? fail(c, rc, "association FC launch failed") : APSE_OK;
+    }
     rc = run_plan(c, c->embedfc, batch, s);
     if (rc) return rc;
     rc = apse_k_l2_normalize(c->emb_raw, (float*)(r + c->lay.embedding), g.embed_dim, total, NM, s);

@@ -360,6 +360,94 @@ __global__ __launch_bounds__(64) void l2_normalize_rows(const float* __restrict_
     for (int i = lane; i < D; i += 64) y[(size_t)r * D + i] = x[(size_t)r * D + i] / nrm;
 }
 
+// ---- AssociationHead FC (dcnn/networks/association_head.py:16-27: Linear(256 * 10 * 10 -> 128) + F.normalize) --------------------
+// A handful of rows (one per detection) against a 13 MB filter matrix: a pure filter stream.  As a split-K convolution it was a
+// 31 us launch of 128 blocks + a reduce pass + the normalise kernel (42 us, three kernel boundaries).  Here every block takes a
+// 128-wide slice of K for ALL output channels: its filter slice (N x 512 B) goes global -> registers once, the live rows are
+// multiplied in chunks of 16 with v_mfma_f32_16x16x4_f32 (exact f32), partial sums go to a [slice][row][N] workspace; the
+// second kernel adds the slices in a fixed tree (bitwise reproducible), the bias, and normalises the row.
+template <int TPW>   // 16-column tiles per wave: N = 64 TPW
+__global__ __launch_bounds__(256) void assoc_fc_slices(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ ws,
+                                                       const int* __restrict__ total, int n_max, int K) {
+    constexpr int N = 64 * TPW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, ks = lane >> 4;
+    const int live = total ? (*total < n_max ? *total : n_max) : n_max;
+    if (live <= 0) return;
+    const size_t kbase = (size_t)blockIdx.x * 128 + 4 * ks;
+    f32x4 b[TPW][8];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[t][j] = *reinterpret_cast<const f32x4*>(w + (size_t)((wave * TPW + t) * 16 + col) * K + kbase + 16 * j);
+    for (int m0 = 0; m0 < live; m0 += 16) {
+        const int row = m0 + col;
+        const bool in = row < live;
+        f32x4 a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)(in ? row : 0) * K + kbase + 16 * j);
+            a[j] = in ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 acc[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], b[t][j][i], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 4 * ks + r;
+                if (m < live) ws[((size_t)blockIdx.x * n_max + m) * N + (wave * TPW + t) * 16 + col] = acc[t][r];
+            }
+    }
+}
+
+// one block of 1024 threads per live row: the slices are added in a FIXED tree -- 1024 / N groups of consecutive slices, each
+// summed in order (eight loads in flight), then the groups in order -- + bias -> raw; F.normalize(raw, eps = 1e-12) -> y
+__global__ __launch_bounds__(1024) void assoc_fc_finish(const float* __restrict__ ws, const float* __restrict__ bias, float* __restrict__ raw,
+                                                        float* __restrict__ y, const int* __restrict__ total, int n_max, int N, int slices) {
+    __shared__ float grp[1024];
+    __shared__ float part[4];
+    const int r = blockIdx.x;
+    if (r >= n_max || (total && r >= *total)) return;
+    const int groups = 1024 / N;                       // 4, 8 or 16
+    const int n = threadIdx.x % N, g = threadIdx.x / N;
+    const int per = (slices + groups - 1) / groups;
+    const int s_lo = g * per, s_hi = (s_lo + per) < slices ? (s_lo + per) : slices;
+    float v = 0.f;
+    for (int s0 = s_lo; s0 < s_hi; s0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (s0 + u < s_hi) ? ws[((size_t)(s0 + u) * n_max + r) * N + n] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    grp[g * N + n] = v;
+    __syncthreads();
+    float sq = 0.f;
+    if (threadIdx.x < N) {
+        v = grp[n];
+        for (int q = 1; q < groups; ++q) v += grp[q * N + n];
+        v += bias ? bias[n] : 0.f;
+        raw[(size_t)r * N + n] = v;
+        sq = v * v;
+    }
+    if (threadIdx.x < 256) {
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+    }
+    __syncthreads();
+    float nrm = sqrtf(part[0] + part[1] + part[2] + part[3]);
+    nrm = nrm < 1e-12f ? 1e-12f : nrm;
+    if (threadIdx.x < N) y[(size_t)r * N + n] = v / nrm;
+}
+
 // D[o][n] = sum_k (a[o][k] - b[n][k])^2, one wave per pair.
 __global__ __launch_bounds__(64) void sqdist_matrix(const float* __restrict__ a, const float* __restrict__ b, int O, int N,
                                                     int D, float* __restrict__ out) {
@@ -413,6 +501,19 @@ int apse_k_roi_align_masked(const void* feat, int st, int H, int W, int img0, co
 int apse_k_l2_normalize(const float* x, float* y, int D, const int* total, int n_max, hipStream_t s) {
     if (n_max <= 0) return APSE_OK;
     hipLaunchKernelGGL(l2_normalize_rows, dim3(n_max), dim3(64), 0, s, x, y, D, total, n_max);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+// x [n_max][K] f32, w [>= N][K] f32, ws [K / 128][n_max][N]; raw / y [n_max][N].  Eligible: K % 128 == 0, N in {64, 128, 256}.
+bool apse_assoc_fc_ok(int K, int N) { return K > 0 && (K & 127) == 0 && (N == 64 || N == 128 || N == 256); }
+int apse_k_assoc_fc(const float* x, const float* w, const float* bias, float* ws, const int* total, int n_max, int K, int N, float* raw,
+                    float* y, hipStream_t s) {
+    if (!apse_assoc_fc_ok(K, N)) return APSE_E_INVALID;
+    if (n_max <= 0) return APSE_OK;
+    const int slices = K / 128;
+    if (N == 64) hipLaunchKernelGGL(assoc_fc_slices<1>, dim3(slices), dim3(256), 0, s, x, w, ws, total, n_max, K);
+    else if (N == 128) hipLaunchKernelGGL(assoc_fc_slices<2>, dim3(slices), dim3(256), 0, s, x, w, ws, total, n_max, K);
+    else hipLaunchKernelGGL(assoc_fc_slices<4>, dim3(slices), dim3(256), 0, s, x, w, ws, total, n_max, K);
+    hipLaunchKernelGGL(assoc_fc_finish, dim3(n_max), dim3(1024), 0, s, ws, bias, raw, y, total, n_max, N, slices);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_sqdist(const float* a, const float* b, int O, int N, int D, float* out, hipStream_t s) {

@@ -375,6 +375,29 @@ def test_fused_stem_pool_equals_two_kernel_form(setup, dtype, size, monkeypatch)
     assert got[0][2] == got[1][2]
 
 
+def test_assoc_fc_sliced_equals_conv_form(setup, logdir, monkeypatch):
+    """The association FC as K slices + ordered reduction + normalise (roi.hip, apse_k_assoc_fc) against the split-K convolution +
+    reduce + l2_normalize kernels (APSE_NO_ASSOC_FC, read when a context is built): same f32 products, another summation order."""
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    frame = setup["seq"].frame(2)
+    got = []
+    for conv_form in (False, True):
+        if conv_form:
+            monkeypatch.setenv("APSE_NO_ASSOC_FC", "1")
+        else:
+            monkeypatch.delenv("APSE_NO_ASSOC_FC", raising=False)
+        tr = RcnnTracker(_cfg(), FRAME, setup["asd"], detector_state=setup["sd"])
+        tr.predictor(frame)
+        rec = tr.predictor.model.last_results.record(0)
+        got.append((rec["embeddings"].copy(), rec["boxes"].copy()))
+    assert got[0][0].shape == got[1][0].shape and got[0][0].shape[0] > 0
+    assert np.array_equal(got[0][1], got[1][1])
+    d = float(np.abs(got[0][0] - got[1][0]).max())
+    _log(logdir, "assoc_fc_sliced_vs_conv", dict(n=int(got[0][0].shape[0]), max_abs=d))
+    assert d < 1e-6                                        # unit-norm 128-vectors: a few f32 ulps
+    assert np.allclose(np.linalg.norm(got[0][0], axis=1), 1.0, atol=1e-6)
+
+
 def test_results_independent_of_history(setup, logdir):
     from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
     from hip_helpers import history_independence
