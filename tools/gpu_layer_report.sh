@@ -4,7 +4,7 @@
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-events --throughput-depth 0 "$@" > $R/gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-events --throughput-depth 0 --no-entrypoint "$@" > $R/gpurun_out/prof_$tag.log 2>&1
 cd $R
 f=$(find gpurun_out/prof_$tag -name "*kernel_trace.csv" | head -1)
 nd=$(python - <<PY

@@ -58,10 +58,12 @@ items = []
 for r in fr:
     kn = r['Kernel_Name']
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    if any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'stem_s2d_pool16', 'conv_skinny16')):
+    if any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'stem_s2d_pool16', 'conv_skinny16', 'assoc_fc_slices')):
         # the __bf16 template argument defeats rocprofv3's demangler: fall back to the raw name
         if 'stem_s2d_pool16' in kn:
             lab = 'stem+pool fused'
+        elif 'assoc_fc_slices' in kn:
+            lab = 'K slices + finish'
         elif 'conv_skinny16' in kn:
             lab = 'skinny' + (kn.split('<')[1].split('>')[0] if '<' in kn else '')
         elif 'conv1x1_stream' in kn:
@@ -71,7 +73,7 @@ for r in fr:
         else:
             lab = kn.split('<')[1].split('>')[0] if '<' in kn else kn.split('conv_igemm')[1][:28]
         items.append([lab[-22:], d, r['Grid_Size_X'], r['Grid_Size_Y']])
-    elif 'conv_splitk_reduce' in kn.split('(')[0] and items:
+    elif ('conv_splitk_reduce' in kn.split('(')[0] or 'assoc_fc_finish' in kn.split('(')[0]) and items:
         items[-1][1] += d
 assert len(items) == len(layers), (len(items), len(layers))
 agg = collections.OrderedDict()
@@ -88,7 +90,7 @@ for k, (d, fl, n) in agg.items():
 others = collections.Counter()
 for r in fr:
     kn = r['Kernel_Name']
-    if not any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'conv_splitk_reduce', 'stem_s2d_pool16', 'conv_skinny16')):
+    if not any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'conv_splitk_reduce', 'stem_s2d_pool16', 'conv_skinny16', 'assoc_fc_')):
         others[kn.split('(')[0].replace('void ', '')[:40]] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 print('non-conv kernels:')
 for k, v in others.most_common(14):
