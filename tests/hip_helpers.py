@@ -208,10 +208,21 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
     Scores are compared in the space the noise is uniform in: the RPN's objectness values are logits already; the box branch's
     are softmax probabilities, whose response to the same logit noise is p (1 - p) -- 0.25 at the 0.5 threshold, 0.09 at 0.9 --
     so they are compared as log(p / (1 - p)) (``score_thr`` given).  Items are paired with ``_same_matrix``.
-    "Within eps" means within BAND x the largest deviation seen on the other candidates (BAND = 1.5: the disputed item is
-    one more draw from the same noise, and the maximum of ~10^2 draws is exceeded by a fresh one about once in 10^2).
+    "Within eps" means within the 99.9th PERCENTILE of the deviations measured on the other candidates (round 3; rounds 1-2
+    used 1.5 x their MAXIMUM, which for bf16 was a band of 0.35 logits -- wide enough to wave through a real 0.1-0.3 logit
+    kernel error; the 99.9th percentile of the same ~2 700 samples is ~0.15).  Every disputed item also reports where it sits
+    in that noise: ``sigma_of_the_others`` (RMS deviation) and ``z`` = its own deviation / sigma.
     Everything else -- including "the other run has no such candidate" -- is returned in ``unexplained``."""
-    BAND = 1.5
+    BAND = 1.0
+    Q = 0.999
+
+    def qband(v):
+        v = torch.as_tensor(v, dtype=torch.double).reshape(-1)
+        return float(torch.quantile(v, Q)) if v.numel() else 0.0
+
+    def rms(v):
+        v = torch.as_tensor(v, dtype=torch.double).reshape(-1)
+        return float(torch.sqrt((v * v).mean())) if v.numel() else 0.0
     if score_thr is not None:
         def sp(v):
             return torch.logit(torch.as_tensor(v, dtype=torch.double).clamp(1e-7, 1 - 1e-7))
@@ -232,6 +243,7 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
     pair_ds = torch.zeros((0,))
     sub_box = torch.zeros((0, 4))
     du = torch.zeros((0, 0), dtype=torch.double)
+    du_band = torch.zeros((0, 0), dtype=torch.bool)
     eps_s = eps_box = eps_iou = 0.0
     n_pairs = 0
     if ca[0].shape[0] and cb[0].shape[0]:
@@ -259,9 +271,11 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
             ua, ub = _iou_matrix(sub_box, sub_box), _iou_matrix(cb[0][ib], cb[0][ib])
             band = (ua > 0.3) & (ua < 0.8)
             du = (ua - ub).abs() * band
+            du_band = band
             if int(band.sum()):
                 eps_iou = float(du.max())
     rep.update(cand_pairs=n_pairs, eps_score=eps_s, eps_box_px=eps_box, eps_iou=eps_iou,
+               score_noise_q999=qband(pair_ds), score_noise_rms=rms(pair_ds), iou_noise_q999=qband(du[du_band]) if du_band.numel() else 0.0,
                score_noise_largest=[round(float(v), 5) for v in torch.sort(pair_ds, descending=True).values[:8]],
                score_space="logit of the probability" if score_thr is not None else "as given (logits)")
     # pair the kept items
@@ -298,7 +312,8 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
         sel = (yc == cat).nonzero()[:, 0]
         uu = _same_matrix(box[None], yb[sel])[0] if sel.numel() else torch.zeros(0, dtype=torch.double)
         far = _iou_matrix(box[None], pair_box)[0] < 0.5 if pair_box.shape[0] else torch.zeros(0, dtype=torch.bool)
-        eps_here = float(pair_ds[far].max()) if int(far.sum()) else 0.0       # score noise of the other candidates
+        eps_here = qband(pair_ds[far]) if int(far.sum()) else 0.0       # score noise of the other candidates: 99.9th percentile
+        sig_here = rms(pair_ds[far]) if int(far.sum()) else 0.0
         if sel.numel() and float(uu.max()) < match_iou:
             # noisy runs (bf16 moves small boxes by several pixels): the same candidate may fall below match_iou.  Accept one
             # that still overlaps by >= 0.7 AND carries the same score within the measured score noise
@@ -323,7 +338,8 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
         c = sel[int(uu.argmax())]
         sy = float(ys[c])
         dsy = abs(spf(s) - spf(sy))                          # in the comparison space (logits)
-        item.update(other_score=sy, score_diff=round(dsy, 6), eps_score_of_the_others=round(eps_here, 6))
+        item.update(other_score=sy, score_diff=round(dsy, 6), eps_score_of_the_others=round(eps_here, 6),
+                    sigma_of_the_others=round(sig_here, 6), z=round(dsy / sig_here, 2) if sig_here > 0 else None)
         if score_thr is not None:
             item.update(score_margin_to_thr=round(s - score_thr, 6), other_margin_to_thr=round(sy - score_thr, 6))
             if sy <= score_thr:
@@ -366,7 +382,9 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
                 return item, False
             u_x = float(_iou_matrix(box[None], X["boxes"][jx][None])[0, 0])
             other = _iou_matrix(box[None], sub_box)[0] < match_iou if sub_box.shape[0] else torch.zeros(0, dtype=torch.bool)
-            eps_u = float(du[other][:, other].max()) if int(other.sum()) else 0.0      # IoU noise of the pairs not involving it
+            sub = du[other][:, other][du_band[other][:, other]] if int(other.sum()) else torch.zeros(0)
+            eps_u = qband(sub)                                                          # IoU noise of the pairs not involving it: 99.9th percentile
+            item.update(sigma_iou_of_the_others=round(rms(sub), 6), z_iou=round((u_y - u_x) / rms(sub), 2) if rms(sub) > 0 else None)
             item.update(iou_here=round(u_x, 6), nms_margin_here=round(u_x - nms_thr, 6), iou_diff=round(u_y - u_x, 6),
                         eps_iou_of_the_others=round(eps_u, 6))
             return item, (u_x <= nms_thr and (u_y - u_x) <= max(BAND * eps_u, 1e-6))

@@ -75,7 +75,7 @@ def test_single_frame_stages(setup, logdir):
         d = float((got - ref).abs().max() / ref.abs().max())
         _log(logdir, "feat/" + k, dict(rel=d, shape=list(got.shape)))
         assert got.shape == ref.shape
-        assert d < 1e-4, (k, d)
+        assert d < 5e-6, (k, d)               # [observed on MI355X, round 2: 2.3e-6 (p2), 6.5e-7 .. 8.1e-7 (p3..p6)]
     # ---- proposals
     res = model.last_results
     P = int(res.prop_count[0])
@@ -85,15 +85,18 @@ def test_single_frame_stages(setup, logdir):
     assert P == ref_props.shape[0]
     dprop = float((props - ref_props).abs().max())
     _log(logdir, "rpn_boxes", dict(max_abs=dprop))
-    assert dprop < 1e-2                       # pixels in the 252x448 image; same anchors selected in the same order
+    assert dprop < 1.3e-4, dprop              # [observed 6.1e-5 px = 1 ulp at x ~ 400] pixels in the 252x448 image; same anchors selected in the same order
     # ---- detections
     n = len(inst)
     _log(logdir, "dets", dict(n=n, ref_n=int(post["boxes"].shape[0]), scores=[float(s) for s in inst.scores[:8]],
                               ref_scores=[float(s) for s in post["scores"][:8]]))
     assert n == post["boxes"].shape[0]
     assert torch.equal(inst.pred_classes, post["classes"])
-    assert float((inst.pred_boxes.tensor - post["boxes"]).abs().max()) < 2e-2      # frame pixels
-    assert float((inst.scores - post["scores"]).abs().max()) < 1e-5
+    dbox = float((inst.pred_boxes.tensor - post["boxes"]).abs().max())
+    dscore = float((inst.scores - post["scores"]).abs().max())
+    _log(logdir, "dets_delta", dict(box_max_abs_px=dbox, score_max_abs=dscore))
+    assert dbox < 5e-4, dbox                   # north_star: 1e-3 on pixel positions
+    assert dscore < 2e-6, dscore               # [observed 9.5e-7]
     # ---- masks: identical pixel sets up to threshold-edge pixels; centroids equal or off by one
     bad_px = 0
     for k in range(n):
@@ -106,13 +109,13 @@ def test_single_frame_stages(setup, logdir):
         if m.mass and not np.isnan(rc[0]):
             assert abs(m.centroid[0] - rc[0]) <= 1 and abs(m.centroid[1] - rc[1]) <= 1
     _log(logdir, "masks", dict(mismatched_pixels=bad_px, total=int(sum(int(m.mass) for m in inst.pred_masks))))
-    assert bad_px <= max(4, n)                 # >= 0.5 threshold on f32 bilinear values: a few edge pixels may flip
+    assert bad_px <= 2                         # [observed 0 of 7505] >= 0.5 threshold on f32 bilinear values: an edge pixel may flip
     # ---- embeddings (unit vectors)
     if n:
         emb = torch.from_numpy(inst._record["embeddings"])
         de = float((emb - post["emb"]).abs().max())
         _log(logdir, "emb", dict(max_abs=de))
-        assert de < 1e-4
+        assert de < 1e-6                       # [observed 4.9e-7] unit vectors
 
 
 def test_sequence_ids_and_csv(setup, logdir, tmp_path):
@@ -139,7 +142,7 @@ def test_sequence_ids_and_csv(setup, logdir, tmp_path):
         olines.append(oline)
     same = sum(1 for a, b in zip(lines, olines) if a == b)
     _log(logdir, "seq/csv", dict(same_lines=same, n=len(lines), sample=lines[0][:120], ref=olines[0][:120]))
-    assert same >= len(lines) - 1              # integer cells; a threshold-edge pixel may move one centroid by 1
+    assert same == len(lines)                  # [observed 6 of 6] integer cells: every line equal to the oracle's text
 
 
 @pytest.mark.parametrize("depth,want_masks", [(3, False), (2, True)])
@@ -205,17 +208,19 @@ def test_bf16_mode_vs_bf16_oracle(setup, logdir, dtype, storage):
         _log(logdir, dtype + ("/s16" if storage else "/s32") + "/feat/" + k, dict(rel_max=d, rel_mean=mean))
         assert d < 3e-2 and mean < 1e-2        # bf16 noise floor: ~2^-9 after the roundings decorrelate
     n, rn = len(inst), int(post["boxes"].shape[0])
-    _log(logdir, dtype + ("/s16" if storage else "/s32") + "/dets", dict(n=n, ref_n=rn, scores=[round(float(s), 4) for s in inst.scores],
-                                   ref=[round(float(s), 4) for s in post["scores"]]))
-    assert abs(n - rn) <= 2
-    matched = 0
-    for k in range(n):
-        b = inst.pred_boxes.tensor[k]
-        d = (post["boxes"] - b).abs().max(dim=1).values if rn else torch.tensor([])
-        if rn and float(d.min()) < 2.0:
-            matched += 1
-    _log(logdir, dtype + ("/s16" if storage else "/s32") + "/matched", dict(matched=matched, n=n))
-    assert matched >= min(n, rn) - 2
+    from hip_helpers import explain_frame
+    rep, unexplained = explain_frame(tr.predictor.model, post)
+    tag = dtype + ("/s16" if storage else "/s32")
+    _log(logdir, tag + "/dets", dict(n=n, ref_n=rn, scores=[round(float(s), 4) for s in inst.scores],
+                                     ref=[round(float(s), 4) for s in post["scores"]], matched=rep["box"]["matched"],
+                                     only=rep["box"]["only"], rpn_only=len(rep["rpn"]["only"]), unexplained=unexplained,
+                                     noise_q999_logit=rep["box"]["score_noise_q999"], noise_rms_logit=rep["box"]["score_noise_rms"]))
+    # like the 4K test: the two runs keep the same detections except for candidates that sit inside the measured 16-bit noise
+    # (99.9th percentile of the other candidates' deviations) of a discrete decision; every such case is proven one by one
+    assert not unexplained, unexplained
+    assert rep["box"]["matched"] >= 1 and rep["box"]["matched"] >= min(n, rn) - len(rep["box"]["only"])
+    # [observed round 2: 6 of 6 kept in all four variants, scores within 2.3e-3 (bf16) / 4e-4 (f16)]
+    assert rep["box"]["matched_score_max_abs"] < (5e-3 if dtype == "bf16" else 1e-3)
 
 
 def test_no_detections_and_full_list(setup, logdir):
@@ -331,20 +336,21 @@ def test_config3_like_batch4_bf16_with_preproc(setup, logdir, golden_dir):
     frames = [setup["seq"].frame(t) for t in range(4)]
     out = tr.predictor.predict_batch(frames, want_masks=False)[0]
     oracle = DetectorOracle(setup["sd"], dict(depth_blocks=BLOCKS, min_size=256, max_size=448, bf16=True, storage16=True))
-    tot = matched = 0
+    tot = matched = only = 0
     for b in range(4):
         pre = op.preprocess_img(frames[b], cam_small["mtx"], cam_small["dist"])
         img = np.asarray(Image.fromarray(pre).resize((setup["iw"], setup["ih"]), Image.BILINEAR))
         post = oracle.inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), FRAME[0], FRAME[1])
         inst = out[b]["instances"]
         n, rn = len(inst), int(post["boxes"].shape[0])
-        assert abs(n - rn) <= 2
-        for k in range(n):
-            tot += 1
-            if rn and float((post["boxes"] - inst.pred_boxes.tensor[k]).abs().max(dim=1).values.min()) < 2.0:
-                matched += 1
-    _log(logdir, "config3", dict(dets=tot, matched=matched))
-    assert matched >= int(0.95 * tot)              # 16-bit noise floor flips a few near-threshold candidates
+        from hip_helpers import explain_frame
+        rep, unexplained = explain_frame(tr.predictor.model, post, b=b)
+        assert not unexplained, (b, unexplained)       # every difference of the kept sets sits inside the measured bf16 noise of a decision
+        tot += n
+        matched += rep["box"]["matched"]
+        only += len(rep["box"]["only"])
+    _log(logdir, "config3", dict(dets=tot, matched=matched, only_one_run=only))
+    assert tot > 0 and matched >= tot - only
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])

@@ -53,13 +53,13 @@ def test_full_frame_vs_oracle(env, logdir):
     img = np.asarray(Image.fromarray(frame).resize((iw, ih), Image.BILINEAR))
     torch.set_num_threads(_threads())
     post = DetectorOracle(env["sd"]).inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), *FRAME)
-    # Bars: each limit is <= 10x what this test observes on MI355X (logged below; round-2 observations in brackets) and every
-    # float limit sits inside north_star's 1e-3 (pixel positions / distances), index results are exact.
+    # Bars: each limit is about 2x what this test observes on MI355X (logged below; observations in brackets); index results are
+    # exact; the one float that misses north_star's 1e-3 (rescaled box corners, 1.22e-3 px) says so in its assert.
     for k in ("p2", "p4", "p6"):
         got, ref = feats[k].cpu(), post["features"][k]
         d = float((got - ref).abs().max() / ref.abs().max())
         _log(logdir, "feat/" + k, dict(rel=d))
-        assert d < 3e-5                                   # [2.8e-6] f32 through 104 convolutions, different sum order
+        assert d < 6e-6                                   # [2.8e-6] f32 through 104 convolutions, different sum order
     model = tr.predictor.model
     P = int(model.last_results.prop_count[0])
     ref_props = post["proposals"]["boxes"]
@@ -73,7 +73,7 @@ def test_full_frame_vs_oracle(env, logdir):
     _log(logdir, "rpn", dict(P=P, ref_P=int(ref_props.shape[0]), rows_equal=same_p, rows_max_abs_when_equal=float(row_err[row_err < 1e-3].max()),
                              set_max_abs=set_err))
     assert same_p >= P - 12                               # [994 of 1000 rows in place, 6 swapped]
-    assert float(row_err[row_err < 1e-3].max()) < 1e-3 and set_err < 5e-3      # [6.7e-4 px on coordinates up to 1333: 11 ulp]
+    assert float(row_err[row_err < 1e-3].max()) < 1e-3 and set_err < 1.4e-3    # [6.7e-4 px on coordinates up to 1333: 11 ulp]
     n = len(inst)
     from hip_helpers import explain_frame
     rep, unexplained = explain_frame(model, post)
@@ -88,9 +88,10 @@ def test_full_frame_vs_oracle(env, logdir):
     # [1.22e-3 px] box corners in 4K frame pixels = 4.3e-4 px in the resized image x 2.88: 5 f32 ulps at x ~ 3000.  north_star's
     # 1e-3 is met in the resized image the network works in and missed by 0.2e-3 px on the rescaled corners; the pixel
     # positions the CSV carries (integer centroids / closest points) are exact (test_4k_sequence_ids_and_csv_vs_oracle).
-    assert db < 1e-2
-    assert ds < 3e-5                                      # [2.8e-6]
-    assert rep["box"]["eps_score"] < 3e-5 and rep["box"]["eps_box_px"] < 1e-2     # [2.8e-6, 8.5e-4] every candidate above 0.3, not only the kept ones
+    assert db < 2.5e-3, ("box corners differ from the oracle by %.3e frame px; observed 1.22e-3 in round 2, which already MISSES "
+                         "north_star's 1e-3 by 0.22e-3 (5 f32 ulps at x ~ 3000); this bar is 2x that observation" % db)
+    assert ds < 4e-6                                      # [1.6e-6]
+    assert rep["box"]["eps_score"] < 6e-5 and rep["box"]["eps_box_px"] < 2e-3     # [2.6e-5 logits, 9.2e-4 px] every candidate above 0.02, not only the kept ones
     bad = tot = 0
     for k in range(n):
         m = inst.pred_masks[k]
@@ -98,13 +99,13 @@ def test_full_frame_vs_oracle(env, logdir):
         bad += int((m.window().cpu() != post["mask_windows"][k]).sum())
         tot += int(m.mass)
     _log(logdir, "masks", dict(mismatched=bad, total=tot))
-    assert bad <= 40                                      # [4 of 130 557] >= 0.5 on f32 bilinear values: edge pixels may flip
+    assert bad <= 8                                       # [4 of 130 557] >= 0.5 on f32 bilinear values: edge pixels may flip
     if n:
         rois = otr.features_rois(post["features"]["p2"], post["boxes"], FRAME[1])
         emb = otr.association_head(rois, env["asd"]["fc.weight"], env["asd"]["fc.bias"])
         de = float((torch.from_numpy(inst._record["embeddings"]) - emb).abs().max())
         _log(logdir, "emb", dict(max_abs=de))
-        assert de < 6e-6                                  # [6.0e-7] unit vectors
+        assert de < 1.3e-6                                # [6.1e-7] unit vectors
 
 
 def test_determinism_and_batch_equivalence(env):
@@ -393,3 +394,107 @@ def test_config2_static64_csv_vs_oracle(env, logdir, tmp_path, golden_dir):
     assert [c.split(" ")[-1] for c in got[1].split(",")] == [c.split(" ")[-1] for c in ref[1].split(",")]      # frame, cent_x, cent_y, clos_x, ...
     data = csv_log.read_centroid_data(str(path))
     assert len(data) == 64 and all(len(r) == 17 for r in data) and [r[0] for r in data] == list(range(64))
+
+
+def _ids_have_gap(ids_per_frame):
+    """ids that are present, then absent for at least one frame, then present again (re-association after absence)."""
+    out = []
+    for i in sorted({i for ids in ids_per_frame for i in ids}):
+        seen = [i in ids for ids in ids_per_frame]
+        first, last = seen.index(True), len(seen) - 1 - seen[::-1].index(True)
+        if not all(seen[first:last + 1]):
+            out.append(i)
+    return out
+
+
+def test_4k_dynamic16_departure_and_return_vs_oracle(env, logdir):
+    """A 16-frame 3840x2160 dynamic run (every 4th frame of the synthetic sequence: vehicle 1 is out of the picture in frames
+    5..9 and back from frame 10) through RcnnTracker.next_frame against the oracle's detector + tracker: track ids per frame
+    and the CSV text -- including the BLANK cells of an absent id and the id an object gets back when it is re-associated after
+    its absence (visualize_uav.py:131-141, rcnn_tracker.py:136-147; the shipped data/dynamic_dcnn_data.csv has 1 536 blank
+    cells) -- must be equal.  Oracle parity itself is unpinned for the detector rows."""
+    from PIL import Image
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from oracle import tracker as otr
+    from oracle.detector import DetectorOracle, resize_shape
+    torch.set_num_threads(_threads())
+    cfg = env["cfg"].clone()
+    cfg.APSE.MAX_BATCH = 1
+    tr = RcnnTracker(cfg, FRAME, env["asd"], detector_state=env["sd"])
+    oracle = DetectorOracle(env["sd"])
+    otk = otr.TrackerOracle()
+    ih, iw = resize_shape(*FRAME)
+    ids_hip, ids_ref, lines, olines = [], [], [], []
+    for k in range(16):
+        frame = env["seq"].frame(4 * k)
+        objs = tr.next_frame(frame)
+        lines.append(tr.log_line(objs, 1, k)[0])
+        ids_hip.append(list(objs.ids) if len(objs) else [])
+        img = np.asarray(Image.fromarray(frame).resize((iw, ih), Image.BILINEAR))
+        post = oracle.inference(torch.as_tensor(img.astype("float32").transpose(2, 0, 1)), *FRAME)
+        rois = otr.features_rois(post["features"]["p2"], post["boxes"], FRAME[1])
+        emb = otr.association_head(rois, env["asd"]["fc.weight"], env["asd"]["fc.bias"])
+        orec = otk.next_frame(dict(boxes=post["boxes"], scores=post["scores"], classes=post["classes"],
+                                   masks=list(zip(post["mask_windows"], post["mask_rects"])), emb=emb))
+        olines.append(otr.log_oneline(orec, 1, k)[0])
+        ids_ref.append(orec["ids"])
+    gaps = _ids_have_gap(ids_ref)
+    blank_cells = sum(1 for ln in olines for c in ln.split(",")[1:] if c == "")
+    same = sum(a == b for a, b in zip(lines, olines))
+    _log(logdir, "dyn16_4k", dict(ids=ids_hip, ref_ids=ids_ref, same_lines=same, ids_with_gap=gaps, blank_cells=blank_cells))
+    assert ids_hip == ids_ref
+    assert same == 16                          # every CSV line, blank cells included, equal to the oracle's text
+    assert gaps and blank_cells >= 4           # the run does contain a departure, blank cells, and a re-association after absence
+
+
+def _run_sequence_mode(env, frames, dtype, batch, camera):
+    """frames -> per-frame (sorted ids, CSV line, {id: centroid}) with one context of the given mode (frames in batches)."""
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    cfg = env["cfg"].clone()
+    cfg.APSE.MAX_BATCH = batch
+    cfg.APSE.DTYPE = dtype
+    cfg.APSE.STORAGE16 = dtype != "f32"
+    tr = RcnnTracker(cfg, FRAME, env["asd"], detector_state=env["sd"])
+    if camera is not None:
+        tr.predictor.set_camera(camera)
+    out = []
+    for lo in range(0, len(frames), batch):
+        dets = [o["instances"] for o in tr.predictor.predict_batch(frames[lo:lo + batch], want_masks=False)[0]]
+        for j, d in enumerate(dets):
+            tr.frame_count += 1
+            objs = tr._finish_frame(d, None, host_replay=True)
+            ids = list(objs.ids) if len(objs) else []
+            cents = {i: tuple(int(v) for v in m.centroid) for i, m in zip(ids, objs.pred_masks)} if ids else {}
+            out.append((sorted(ids), tr.log_line(objs, 1, lo + j)[0], cents))
+    return out
+
+
+def test_16bit_modes_sequence_drift_vs_f32(env, logdir, golden_dir):
+    """What bf16 / fp16 do to ids over a SEQUENCE (BASELINE configs[2] / [4] against configs[1]'s precision): the 64-frame
+    3840x2160 dynamic sequence through HIP-bf16 (batch 4, undistort + gamma fused) and HIP-fp16 (batch 8), each against
+    HIP-f32 on the same input (f32 is the oracle-checked mode).  Reported per mode (gpurun_out/seq_drift.json and DESIGN.md
+    section 5): frames whose id set equals f32's, frames whose CSV line is identical, largest centroid difference of an id both
+    runs hold.  16-bit rounding moves scores by ~1e-2 (fp16) / ~1e-1 (bf16) logits, so detections near the 0.5 threshold come
+    and go and ids drift after the first such event: this is a characterisation with loose floors, not an equality."""
+    with open(os.path.join(golden_dir, "cam_params.json")) as f:
+        cam = json.load(f)
+    frames = [env["seq"].frame(t) for t in range(64)]
+    table = {}
+    for tag, dtype, batch, camera in (("bf16_b4_preproc", "bf16", 4, cam), ("f16_b8", "f16", 8, None)):
+        ref = _run_sequence_mode(env, frames, "f32", 1, camera)
+        got = _run_sequence_mode(env, frames, dtype, batch, camera)
+        same_ids = sum(a[0] == b[0] for a, b in zip(got, ref))
+        same_lines = sum(a[1] == b[1] for a, b in zip(got, ref))
+        first_diff = next((t for t, (a, b) in enumerate(zip(got, ref)) if a[0] != b[0]), None)
+        n_same = sum(len(a[0]) == len(b[0]) for a, b in zip(got, ref))
+        dc = [max(abs(a[2][i][0] - b[2][i][0]), abs(a[2][i][1] - b[2][i][1])) for a, b in zip(got, ref) for i in a[2] if i in b[2]]
+        table[tag] = dict(frames=64, same_id_set=same_ids, same_csv_line=same_lines, first_frame_with_other_ids=first_diff,
+                          same_detection_count=n_same, common_id_centroid_delta_max_px=max(dc) if dc else None,
+                          common_id_centroid_delta_median_px=float(np.median(dc)) if dc else None,
+                          dets_per_frame_mode=float(np.mean([len(a[0]) for a in got])), dets_per_frame_f32=float(np.mean([len(b[0]) for b in ref])))
+    with open(os.path.join(logdir, "seq_drift.json"), "w") as f:
+        json.dump(table, f, indent=1)
+    _log(logdir, "seq_drift", table)
+    for tag in table:
+        assert table[tag]["dets_per_frame_mode"] > 0
+        assert table[tag]["same_detection_count"] >= 16        # loose floor: the modes are the same detector, not the same bits

@@ -1,0 +1,132 @@
+"""-m gpu: the ingest path of SURVEY 8(f) rank 1 at full size (3840x2160, R-101-FPN, f32) against the plain call.
+
+The reference loop is /root/reference/dcnn/scripts/tests/visualize_uav.py:172-190 (read a frame, `tracker.next_frame(frame)`).
+The build's extension `next_frame(frame, upcoming=next)` / `TrackPredictor.prefetch` stages the NEXT frame through pinned
+memory on a copy stream while the current one computes (engines/track_predictor.py: `h2d_done` / `consumed` events, identity
+match of the announced array, fallback when a prefetch is never used).  That is cross-stream code: every variant below must
+give the per-frame records of the plain loop BYTE FOR BYTE and the same ids / CSV text.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+FRAME = (2160, 3840)
+N = 6
+
+
+@pytest.fixture(scope="module")
+def env():
+    from apse_uav_amd.config import setup_cfg
+    from apse_uav_amd.synthetic import SyntheticSequence
+    from apse_uav_amd.weights import UAV4K_R101_CLS_BIAS, synthetic_association_state, synthetic_detector_state
+    sd = synthetic_detector_state(0, cls_bias=UAV4K_R101_CLS_BIAS)
+    asd = synthetic_association_state(1)
+    cfg = setup_cfg()
+    cfg.APSE.MAX_BATCH = 1
+    seq = SyntheticSequence("dynamic", *FRAME)
+    frames = [seq.frame(7 * t) for t in range(N)]           # the dynamic sequence moves: every frame differs
+    return dict(sd=sd, asd=asd, cfg=cfg, frames=frames)
+
+
+def _tracker(env):
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    return RcnnTracker(env["cfg"], FRAME, env["asd"], detector_state=env["sd"])
+
+
+def _step(tr, frame, t, **kw):
+    from apse_uav_amd.sharding import pack_record
+    objs = tr.next_frame(frame, **kw)
+    return (list(objs.ids) if len(objs) else [], tr.log_line(objs, 1, t)[0], pack_record(tr._last_record, 100, 128).tobytes())
+
+
+@pytest.fixture(scope="module")
+def plain(env):
+    tr = _tracker(env)
+    out = [_step(tr, f, t) for t, f in enumerate(env["frames"])]
+    assert any(o[0] for o in out) and len({o[2] for o in out}) == N        # detections, and the frames really differ
+    return out
+
+
+def test_announced_next_frame_equals_plain(env, plain):
+    """next_frame(f_t, upcoming=f_{t+1}): the upload of frame t+1 runs on the copy stream under frame t's kernels."""
+    tr = _tracker(env)
+    fr = env["frames"]
+    got = [_step(tr, fr[t], t, upcoming=fr[t + 1] if t + 1 < N else None) for t in range(N)]
+    assert [g[2] == p[2] for g, p in zip(got, plain)] == [True] * N
+    assert [(g[0], g[1]) for g in got] == [(p[0], p[1]) for p in plain]
+    # and every prefetch was actually consumed (identity match), not re-uploaded
+    assert tr.predictor._prefetched is None
+
+
+def test_announced_frame_differs_from_given(env, plain):
+    """The caller announces one array and then passes ANOTHER (a copy of the right frame, or a different frame altogether):
+    the stale prefetch must be dropped and the given frame uploaded afresh -- never the announced bytes."""
+    tr = _tracker(env)
+    fr = env["frames"]
+    got = []
+    for t in range(N):
+        if t % 2 == 0:
+            announce = fr[(t + 3) % N]                      # a different frame than the one that will come
+        else:
+            announce = fr[(t + 1) % N].copy()               # the right content in a different array object
+        got.append(_step(tr, fr[t], t, upcoming=announce))
+    assert [g[2] == p[2] for g, p in zip(got, plain)] == [True] * N
+    assert [(g[0], g[1]) for g in got] == [(p[0], p[1]) for p in plain]
+
+
+def test_prefetch_never_consumed(env, plain):
+    """A prefetch that no call ever uses (the caller changed its mind, or the sequence ended): later plain calls, a
+    second unused prefetch on top of it, and a prefetch issued between two plain calls must not disturb any frame."""
+    tr = _tracker(env)
+    fr = env["frames"]
+    got = []
+    for t in range(N):
+        if t in (1, 2):
+            tr.predictor.prefetch(fr[(t + 2) % N])          # announced, never passed
+        if t == 2:
+            tr.predictor.prefetch([fr[0]])                  # a second one over the first
+        got.append(_step(tr, fr[t], t))
+    tr.predictor.prefetch(fr[0])                            # left dangling at the end of the sequence
+    torch.cuda.synchronize()
+    assert [g[2] == p[2] for g, p in zip(got, plain)] == [True] * N
+    assert [(g[0], g[1]) for g in got] == [(p[0], p[1]) for p in plain]
+
+
+def test_mutating_the_consumed_frame_buffer_is_safe(env, plain):
+    """The reference loop reuses its frame variable (`ret, frame = video.read()`): once next_frame has returned, the
+    caller may overwrite the array it passed, with or without a prefetch in flight for the NEXT frame."""
+    tr = _tracker(env)
+    fr = [f.copy() for f in env["frames"]]
+    got = []
+    for t in range(N):
+        got.append(_step(tr, fr[t], t, upcoming=fr[t + 1] if t + 1 < N else None))
+        fr[t][:] = 0                                         # the caller's buffer is its own again
+    assert [g[2] == p[2] for g, p in zip(got, plain)] == [True] * N
+
+
+def test_start_frame_dynamic_equals_tracker_started_there(env, tmp_path):
+    """tools/run_sequence.py --start-frame 3 on the 9-frame DYNAMIC sequence: equal to a fresh tracker fed frames 3..8 with
+    absolute frame numbers (the reference semantics: the tracker's first frame is frame S).  The static-sequence form of this
+    check (rows == rows 3.. of the full run) is in test_gpu_a_multirank.py."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_sequence as rs
+    from apse_uav_amd.synthetic import SyntheticSequence
+    from apse_uav_amd.utils import csv_log
+    out = str(tmp_path / "part.csv")
+    rs.main(["--frames", "9", "--kind", "dynamic", "--size", "2160x3840", "--start-frame", "3", "--out", out])
+    seq = SyntheticSequence("dynamic", *FRAME)
+    tr = _tracker(env)
+    lines = []
+    for t in range(3, 9):
+        objs = tr.next_frame(seq.frame(t))
+        lines.append(tr.log_line(objs, 1, t)[0])
+    ref = str(tmp_path / "ref.csv")
+    csv_log.write_consumer_csv(ref, lines, 1, [2, 3, 4], first_frame=3)
+    with open(out) as f, open(ref) as g:
+        a, b = f.read(), g.read()
+    assert a == b
+    assert [r.split(",")[0] for r in a.split("\n")[2:-1]] == ["3", "4", "5", "6", "7", "8"]

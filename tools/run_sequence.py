@@ -142,7 +142,7 @@ def main(argv=None):
             lines.append(line)
             max_id = max(max_id, hi_id)
         dt = time.perf_counter() - t0
-        csv_log.write_consumer_csv(args.out, lines, args.host_id, [int(v) for v in args.vehicle_ids.split(",")])
+        csv_log.write_consumer_csv(args.out, lines, args.host_id, [int(v) for v in args.vehicle_ids.split(",")], first_frame=first)
         if args.raw_out:
             csv_log.write_raw_csv(args.raw_out, lines, args.host_id, max_id)
         print("wrote %s: %d frames, %d track ids, %d frames in flight, %.1f frames/s incl. frame generation and upload"
@@ -155,7 +155,7 @@ def main(argv=None):
         recs = gather_records(recs, rank, world, torch.device("cuda", local) if backend == "nccl" else torch.device("cpu"))
     if rank == 0:
         lines, max_id = replay(tracker, recs, args.host_id, first_frame=first, fast=(world > 1))
-        csv_log.write_consumer_csv(args.out, lines, args.host_id, [int(v) for v in args.vehicle_ids.split(",")])
+        csv_log.write_consumer_csv(args.out, lines, args.host_id, [int(v) for v in args.vehicle_ids.split(",")], first_frame=first)
         if args.raw_out:
             csv_log.write_raw_csv(args.raw_out, lines, args.host_id, max_id)
         print("wrote %s: %d frames, %d track ids" % (args.out, len(lines), max_id))
