@@ -103,6 +103,7 @@ def load():
         "apse_l2_normalize": ([vp, vp, i, i, vp], i),
         "apse_sqdist": ([vp, vp, i, i, i, vp, vp], i),
         "apse_undistort_gamma": ([vp, vp, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), i, vp, i, i, vp], i),
+        "apse_lab_tables_host": ([vp, vp, C.c_size_t], C.c_size_t),
         "apse_replay_create": ([i, i, f, i], vp),
         "apse_replay_destroy": ([vp], None),
         "apse_replay_step": ([vp, i, i, vp, vp, vp, C.c_char_p, i, vp], i),
@@ -125,7 +126,7 @@ EXPORTS = ["apse_create", "apse_destroy", "apse_last_error", "apse_version", "ap
            "apse_read_results", "apse_copy_mask_window", "apse_feature_shape", "apse_export_feature", "apse_debug_tensor",
            "apse_flops", "apse_profile", "apse_profile_read", "apse_conv_packed_elems", "apse_conv_pack_weight", "apse_conv2d", "apse_maxpool3x3s2",
            "apse_maxpool3x3s2_typed", "apse_roi_align", "apse_roi_align_typed", "apse_roi_pool", "apse_roi_features", "apse_nms_rank", "apse_mask_centroid_dense", "apse_mask_closest_dense",
-           "apse_l2_normalize", "apse_sqdist", "apse_undistort_gamma", "apse_resize_normalize", "apse_replay_create", "apse_replay_destroy",
+           "apse_l2_normalize", "apse_sqdist", "apse_undistort_gamma", "apse_lab_tables_host", "apse_resize_normalize", "apse_replay_create", "apse_replay_destroy",
            "apse_replay_step", "apse_replay_packed", "apse_replay_max_id", "apse_replay_next_id"]
 
 

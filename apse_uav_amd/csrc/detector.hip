@@ -25,8 +25,8 @@ struct PasteParams {
 };
 extern "C" {
 int apse_k_pil_resize(const uint8_t*, uint8_t*, void*, int, uint8_t*, const int*, const int*, int, const int*, const int*, int, int,
-                      int, int, int, int, int, int, const float*, const UndistortParams*, const uint8_t*, const void*, const float*, hipStream_t);
-int apse_k_undistort_build_map(const UndistortParams*, void*, float*, hipStream_t);
+                      int, int, int, int, int, int, const float*, const UndistortParams*, const LabTables*, const void*, hipStream_t);
+int apse_k_undistort_build_map(const UndistortParams*, void*, hipStream_t);
 int apse_k_chw_norm(const float*, void*, int, int, int, int, int, int, const float*, hipStream_t);
 int apse_k_maxpool3x3s2(const void*, void*, int, int, int, int, int, hipStream_t);
 bool apse_assoc_fc_ok(int K, int N);
@@ -57,7 +57,7 @@ int apse_k_mask_paste(const PasteParams*, int, int*, int*, hipStream_t);
 int apse_k_closest_points(const uint64_t*, const int*, const int*, const int*, const int*, const int*, const int*, int, int,
                           int, int, int, int*, unsigned long long*, hipStream_t);
 int apse_k_closest_single(const uint64_t*, int, int, int, float, float, unsigned long long*, hipStream_t);
-int apse_k_undistort_gamma(const UndistortParams*, const uint8_t*, uint8_t*, const uint8_t*, int, hipStream_t);
+int apse_k_undistort_gamma(const UndistortParams*, const uint8_t*, uint8_t*, const LabTables*, int, hipStream_t);
 int apse_k_bits_to_dense(const uint64_t*, const int*, int, int, int, uint8_t*, hipStream_t);
 int apse_k_dense_to_bits(const uint8_t*, int, int, int, uint64_t*, unsigned long long*, hipStream_t);
 }
@@ -113,7 +113,7 @@ struct apse_ctx {
     float* ws_assoc = nullptr;      // [K / 128][max detections][embed_dim]: K slices of the association FC (apse_k_assoc_fc), or nullptr
     float* rf_mask = nullptr; size_t rf_mask_floats = 0;      // apse_roi_features: masks at p2 resolution (grown on demand)
     bool box_maxc_clean = false;
-    UndistortParams cam; bool cam_on = false; uint8_t* cam_lut = nullptr; void* cam_map = nullptr; float* cam_lin = nullptr;     // apse_set_camera: fused undistort + gamma in apse_preprocess_frames
+    UndistortParams cam; bool cam_on = false; LabTables* cam_lut = nullptr; void* cam_map = nullptr;     // apse_set_camera: fused undistort + gamma in apse_preprocess_frames
     int hint_total = 8;      // detections seen in the previous forward: sizes the GRID of the packed-list GEMMs, nothing else
     // per-kernel profiling with HIP events on the caller's stream (bench.py roofline)
     bool prof_on = false; std::vector<hipEvent_t> ev_pool; int ev_used = 0;
@@ -825,7 +825,7 @@ int apse_preprocess_frames(apse_ctx* c, const uint8_t* frames, int batch, void* 
     if (!c->hb) return fail(c, APSE_E_STATE, "resize tables not set");
     const apse_config& g = c->cfg;
     int rc = apse_k_pil_resize(frames, c->rs_tmp, c->t["input"].p, c->t["input"].st, nullptr, c->hb, c->hc, c->hk, c->vb, c->vc, c->vk, batch,
-                               g.frame_h, g.frame_w, g.image_h, g.image_w, c->PH, c->PW, g.pixel_mean, c->cam_on ? &c->cam : nullptr, c->cam_lut, c->cam_map, c->cam_lin,
+                               g.frame_h, g.frame_w, g.image_h, g.image_w, c->PH, c->PW, g.pixel_mean, c->cam_on ? &c->cam : nullptr, c->cam_lut, c->cam_map,
                                (hipStream_t)stream);
     return rc ? fail(c, rc, "pil resize launch failed") : APSE_OK;
 }
@@ -1380,13 +1380,38 @@ static int fill_camera(UndistortParams& p, int H, int W, const double* m, const 
     return APSE_OK;
 }
 
+// Lab tables of a gamma LUT, device-resident for the stateless operator (rebuilt when the LUT changes; the operator is a
+// test / tool entry, a context keeps its own copy)
+static int lab_tables_device(const uint8_t* lut, hipStream_t s, LabTables** out) {
+    static LabTables* dev = nullptr;
+    static LabTables host;
+    static bool have = false;
+    if (!dev && hipMalloc(reinterpret_cast<void**>(&dev), sizeof(LabTables)) != hipSuccess) return APSE_E_NOMEM;
+    if (!have || memcmp(host.lut, lut, 256) != 0) {
+        hipStreamSynchronize(s);                       // an earlier launch may still read the previous tables
+        lab_tables_build(&host, lut);
+        if (hipMemcpy(dev, &host, sizeof(LabTables), hipMemcpyHostToDevice) != hipSuccess) return APSE_E_HIP;
+        have = true;
+    }
+    *out = dev;
+    return APSE_OK;
+}
+
 int apse_undistort_gamma(const uint8_t* src, uint8_t* dst, int B, int H, int W, const double* m, const double* dist, int ndist,
                          const uint8_t* lut, int do_undistort, int do_gamma, void* stream) {
     if (!src || !dst || (do_gamma && !lut)) return APSE_E_INVALID;
     UndistortParams p;
     int rc = fill_camera(p, H, W, m, dist, ndist, do_undistort, do_gamma);
     if (rc) return rc;
-    return apse_k_undistort_gamma(&p, src, dst, lut, B, (hipStream_t)stream);
+    LabTables* lab = nullptr;
+    if (do_gamma && (rc = lab_tables_device(lut, (hipStream_t)stream, &lab))) return rc;
+    return apse_k_undistort_gamma(&p, src, dst, lab, B, (hipStream_t)stream);
+}
+
+size_t apse_lab_tables_host(const uint8_t* lut256, void* out, size_t cap) {
+    if (!lut256 || !out || cap < sizeof(LabTables)) return sizeof(LabTables);
+    lab_tables_build(reinterpret_cast<LabTables*>(out), lut256);
+    return sizeof(LabTables);
 }
 
 int apse_set_camera(apse_ctx* c, const double* m, const double* dist, int ndist, const uint8_t* lut_host, int do_undistort, int do_gamma) {
@@ -1398,17 +1423,22 @@ int apse_set_camera(apse_ctx* c, const double* m, const double* dist, int ndist,
     if (rc) return fail(c, rc, "bad camera parameters (3x3 matrix, <= 14 distortion coefficients, tilt terms zero)");
     hipSetDevice(c->cfg.device);
     if (!c->cam_lut) {
-        c->cam_lut = dalloc<uint8_t>(c, 256);
-        if (!c->cam_lut) return fail(c, APSE_E_NOMEM, "camera LUT alloc");
+        c->cam_lut = dalloc<LabTables>(c, 1);
+        if (!c->cam_lut) return fail(c, APSE_E_NOMEM, "camera Lab tables alloc");
     }
-    if (lut_host) HIPCHK(c, hipMemcpy(c->cam_lut, lut_host, 256, hipMemcpyHostToDevice));
+    if (lut_host) {
+        // the Lab step is integer arithmetic on these tables (preproc_pixel.h); built here once, on the host, in double
+        LabTables host;
+        lab_tables_build(&host, lut_host);
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, hipMemcpy(c->cam_lut, &host, sizeof(LabTables), hipMemcpyHostToDevice));
+    }
     // the remap table depends on the camera only: built here once (f64 rational model per pixel), read per frame (8 B per pixel)
     if (!c->cam_map) {
         c->cam_map = dalloc<uint64_t>(c, (size_t)c->cfg.frame_h * c->cfg.frame_w, false);
-        c->cam_lin = dalloc<float>(c, 256, false);
-        if (!c->cam_map || !c->cam_lin) return fail(c, APSE_E_NOMEM, "camera map alloc");
+        if (!c->cam_map) return fail(c, APSE_E_NOMEM, "camera map alloc");
     }
-    rc = apse_k_undistort_build_map(&p, c->cam_map, c->cam_lin, nullptr);
+    rc = apse_k_undistort_build_map(&p, c->cam_map, nullptr);
     if (rc) return fail(c, rc, "camera map launch failed");
     HIPCHK(c, hipDeviceSynchronize());
     c->cam = p;
@@ -1418,7 +1448,7 @@ int apse_set_camera(apse_ctx* c, const double* m, const double* dist, int ndist,
 int apse_resize_normalize(const uint8_t* frames, uint8_t* tmp, float* out, uint8_t* resized, const int* hb, const int* hc, int hk,
                           const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,
                           const float* mean3, void* stream) {
-    return apse_k_pil_resize(frames, tmp, out, 0, resized, hb, hc, hk, vb, vc, vk, B, H, W, OH, OW, PH, PW, mean3, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    return apse_k_pil_resize(frames, tmp, out, 0, resized, hb, hc, hk, vb, vc, vk, B, H, W, OH, OW, PH, PW, mean3, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -26,15 +26,15 @@ __device__ __forceinline__ int clip8(int v) {
 // and one launch less than undistort_gamma -> pil_resize_h).  Same per-pixel function, same bytes as the two-kernel form.
 template <bool FUSED>
 __device__ __forceinline__ void pil_stage_row(uint8_t* row, const uint8_t* __restrict__ src, int y, int b, int W, size_t src_img_stride,
-                                              const UndistortParams& cam, const uint8_t* __restrict__ lut,
-                                              const int2* __restrict__ cam_map, const float* __restrict__ cam_lin) {
+                                              const UndistortParams& cam, const LabTables* __restrict__ lut,
+                                              const int2* __restrict__ cam_map) {
     const uint8_t* srow = src + (size_t)b * src_img_stride + (size_t)y * W * 3;
     const int nbytes = W * 3;
     if constexpr (FUSED) {
         const uint8_t* frame = src + (size_t)b * src_img_stride;
         for (int x = threadIdx.x; x < W; x += blockDim.x) {
             int c0, c1, c2;
-            undistort_gamma_pixel(cam, frame, lut, x, y, c0, c1, c2, cam_map, cam_lin);
+            undistort_gamma_pixel(cam, frame, lut, x, y, c0, c1, c2, cam_map);
             row[x * 3 + 0] = (uint8_t)c0; row[x * 3 + 1] = (uint8_t)c1; row[x * 3 + 2] = (uint8_t)c2;
         }
     } else
@@ -55,12 +55,12 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp,
                                                     const int* __restrict__ bounds, const int* __restrict__ coef,
                                                     int H, int W, int OW, int ksize, size_t src_img_stride,
-                                                    size_t tmp_img_stride, const UndistortParams cam, const uint8_t* __restrict__ lut,
-                                                    const int2* __restrict__ cam_map, const float* __restrict__ cam_lin) {
+                                                    size_t tmp_img_stride, const UndistortParams cam, const LabTables* __restrict__ lut,
+                                                    const int2* __restrict__ cam_map) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint8_t* row = reinterpret_cast<uint8_t*>(smem);
     const int y = blockIdx.x, b = blockIdx.y;
-    pil_stage_row<FUSED>(row, src, y, b, W, src_img_stride, cam, lut, cam_map, cam_lin);
+    pil_stage_row<FUSED>(row, src, y, b, W, src_img_stride, cam, lut, cam_map);
     __syncthreads();
     uint8_t* orow = tmp + (size_t)b * tmp_img_stride + (size_t)y * OW * 3;
     for (int o = threadIdx.x; o < OW * 3; o += blockDim.x) {
@@ -83,8 +83,8 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void pil_resize_h8(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp,
                                                      const int2* __restrict__ bounds, const int* __restrict__ coef,
                                                      int H, int W, int OW, int ksize, size_t src_img_stride,
-                                                     size_t tmp_img_stride, const UndistortParams cam, const uint8_t* __restrict__ lut,
-                                                     const int2* __restrict__ cam_map, const float* __restrict__ cam_lin) {
+                                                     size_t tmp_img_stride, const UndistortParams cam, const LabTables* __restrict__ lut,
+                                                     const int2* __restrict__ cam_map) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint8_t* row = reinterpret_cast<uint8_t*>(smem);                      // W*3 bytes (+ 32: tap slots past the row end)
     const int y = blockIdx.x, b = blockIdx.y;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void pil_resize_h8(const uint8_t* __restrict__
     // aligned on both sides whatever OW is (1333 * 3 bytes per row: rows start at every alignment)
     const int mis = (int)(reinterpret_cast<uintptr_t>(gdst) & 15);
     uint8_t* orow_l = row + (((size_t)W * 3 + 32 + 15) & ~(size_t)15) + mis;    // OW*3 bytes
-    pil_stage_row<FUSED>(row, src, y, b, W, src_img_stride, cam, lut, cam_map, cam_lin);
+    pil_stage_row<FUSED>(row, src, y, b, W, src_img_stride, cam, lut, cam_map);
     if (threadIdx.x < 32) row[W * 3 + threadIdx.x] = 0;
     __syncthreads();
     for (int ox0 = threadIdx.x; ox0 < OW; ox0 += 512) {
@@ -307,7 +307,7 @@ int apse_k_round16(const float* x, uint16_t* y, size_t n, int dtype, hipStream_t
 }
 int apse_k_pil_resize(const uint8_t* src, uint8_t* tmp, void* out, int out_st, uint8_t* resized_u8, const int* hb, const int* hc,
                       int hk, const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,
-                      const float* mean, const UndistortParams* cam, const uint8_t* lut, const void* cam_map, const float* cam_lin,
+                      const float* mean, const UndistortParams* cam, const LabTables* lut, const void* cam_map,
                       hipStream_t s) {
     if ((W & 3) != 0 || (size_t)W * 3 > 150000) return APSE_E_INVALID;
     UndistortParams none;
@@ -321,16 +321,16 @@ int apse_k_pil_resize(const uint8_t* src, uint8_t* tmp, void* out, int out_st, u
     const int2* map2 = reinterpret_cast<const int2*>(cam_map);
     if (h8 && fused)
         hipLaunchKernelGGL(pil_resize_h8<true>, dim3(H, B), dim3(256), lds8, s, src, tmp, hb2, hc, H, W, OW, hk, (size_t)H * W * 3,
-                           (size_t)H * OW * 3, *cam, lut, map2, cam_lin);
+                           (size_t)H * OW * 3, *cam, lut, map2);
     else if (h8)
         hipLaunchKernelGGL(pil_resize_h8<false>, dim3(H, B), dim3(256), lds8, s, src, tmp, hb2, hc, H, W, OW, hk, (size_t)H * W * 3,
-                           (size_t)H * OW * 3, none, nullptr, nullptr, nullptr);
+                           (size_t)H * OW * 3, none, (const LabTables*)nullptr, (const int2*)nullptr);
     else if (fused)
         hipLaunchKernelGGL(pil_resize_h<true>, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
-                           (size_t)H * W * 3, (size_t)H * OW * 3, *cam, lut, map2, cam_lin);
+                           (size_t)H * W * 3, (size_t)H * OW * 3, *cam, lut, map2);
     else
         hipLaunchKernelGGL(pil_resize_h<false>, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
-                           (size_t)H * W * 3, (size_t)H * OW * 3, none, nullptr, nullptr, nullptr);
+                           (size_t)H * W * 3, (size_t)H * OW * 3, none, (const LabTables*)nullptr, (const int2*)nullptr);
     hipLaunchKernelGGL(pil_resize_v_norm, dim3((OW * 3 + 255) / 256, OH, B), dim3(256), 0, s, tmp, out, out_st, vb, vc, OH, OW, vk,
                        PH, PW, mean[0], mean[1], mean[2], (size_t)H * OW * 3, resized_u8);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;

@@ -8,35 +8,34 @@
 #include "preproc_pixel.h"
 
 __global__ __launch_bounds__(256) void undistort_gamma(const UndistortParams p, const uint8_t* __restrict__ src,
-                                                       uint8_t* __restrict__ dst, const uint8_t* __restrict__ lut) {
+                                                       uint8_t* __restrict__ dst, const LabTables* __restrict__ lab) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     const int b = blockIdx.z;
     if (x >= p.W) return;
     const uint8_t* s = src + (size_t)b * p.H * p.W * 3;
     int c0, c1, c2;
-    undistort_gamma_pixel(p, s, lut, x, y, c0, c1, c2);
+    undistort_gamma_pixel(p, s, lab, x, y, c0, c1, c2);
     uint8_t* o = dst + (((size_t)b * p.H + y) * p.W + x) * 3;
     o[0] = (uint8_t)c0; o[1] = (uint8_t)c1; o[2] = (uint8_t)c2;
 }
 
-// Built once per camera (apse_set_camera): the remap table of undistort_map_pixel and srgb_to_lin of the 256 byte values.
-__global__ __launch_bounds__(256) void undistort_build_map(const UndistortParams p, int2* __restrict__ map, float* __restrict__ lin) {
+// Built once per camera (apse_set_camera): the remap table of undistort_map_pixel.
+__global__ __launch_bounds__(256) void undistort_build_map(const UndistortParams p, int2* __restrict__ map) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (y == 0 && blockIdx.x == 0) lin[threadIdx.x] = pp_srgb_to_lin((float)threadIdx.x / 255.f);
     if (x >= p.W) return;
     int sx, sy, fx, fy;
     undistort_map_pixel(p, x, y, sx, sy, fx, fy);
     map[(size_t)y * p.W + x] = int2{sx, (sy << 10) | (fx << 5) | fy};
 }
 
-extern "C" int apse_k_undistort_build_map(const UndistortParams* p, void* map, float* lin, hipStream_t s) {
-    hipLaunchKernelGGL(undistort_build_map, dim3((p->W + 255) / 256, p->H), dim3(256), 0, s, *p, reinterpret_cast<int2*>(map), lin);
+extern "C" int apse_k_undistort_build_map(const UndistortParams* p, void* map, hipStream_t s) {
+    hipLaunchKernelGGL(undistort_build_map, dim3((p->W + 255) / 256, p->H), dim3(256), 0, s, *p, reinterpret_cast<int2*>(map));
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 
-extern "C" int apse_k_undistort_gamma(const UndistortParams* p, const uint8_t* src, uint8_t* dst, const uint8_t* lut, int B,
+extern "C" int apse_k_undistort_gamma(const UndistortParams* p, const uint8_t* src, uint8_t* dst, const LabTables* lab, int B,
                                       hipStream_t s) {
-    hipLaunchKernelGGL(undistort_gamma, dim3((p->W + 255) / 256, p->H, B), dim3(256), 0, s, *p, src, dst, lut);
+    hipLaunchKernelGGL(undistort_gamma, dim3((p->W + 255) / 256, p->H, B), dim3(256), 0, s, *p, src, dst, lab);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }

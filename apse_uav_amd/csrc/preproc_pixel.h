@@ -5,10 +5,67 @@
 //    k1..k6, p1, p2, s1..s4), rounded half-to-even to 1/32 px;
 //  * remap: INTER_LINEAR with the 15-bit integer weights of OpenCV's fixed-point path, border 0 -- integer arithmetic, bit-exact
 //    with oracle/preproc.py;
-//  * Lab: published CIE formulas in f32 (OpenCV's 8-bit tables are not reproducible here: parity unpinned).
+//  * Lab (round 3): integer and table-driven, in the manner of OpenCV's own 8-bit path (RGB2Lab_b / Lab2RGBinteger: a 256-entry
+//    sRGB -> linear table, a Q12 XYZ matrix, a tabulated cube root, Q15 L / a / b, and on the way back a tabulated inverse gamma
+//    over a 12-bit linear value).  Every step is integer arithmetic on tables built once on the host (lab_tables_build below),
+//    so the bytes equal oracle/preproc.py's, which builds the same tables with numpy (tests/test_host_logic.py compares the
+//    tables entry by entry; tests/test_gpu_ops.py asserts 0 differing bytes at 4K).  OpenCV's exact table constants are not
+//    reproducible here (cv2 absent): parity with OpenCV itself stays unpinned.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
+
+#define LAB_GS 3                          // gamma shift: linear values carry 255 << 3 = 2040 levels
+#define LAB_LIN_MAX 2040
+#define LAB_CBRT_N 3072                   // 256 * 3 / 2 << LAB_GS entries, index = white-normalised X / Y / Z in 1 / 2040
+#define LAB_INV_N 4096                    // inverse gamma over a 12-bit linear value (+ 1 entry for 1.0)
+struct LabTables {
+    uint16_t lin[256];                    // rint(2040 * sRGB EOTF(i / 255))
+    uint16_t cbrt[LAB_CBRT_N];            // rint(32768 * f(i / 2040)), f(t) = t > 0.008856 ? cbrt(t) : 7.787 t + 16 / 116
+    int32_t c[9];                         // rint(4096 * M[r][c] / white[r]): RGB -> XYZ, rows normalised by the D65 white point
+    uint8_t lut[256];                     // the reference's LUT on L: uint8(clip((i / 255)^gamma * 255))
+    uint16_t fy[256];                     // rint(32768 * (L + 16) / 116), L = i * 100 / 255
+    int32_t y[256];                       // rint(32768 * (L > 7.9996248 ? fy^3 : L / 903.3))
+    int32_t at[256], bt[256];             // rint(32768 * (i - 128) / 500), rint(32768 * (i - 128) / 200)
+    int32_t ci[9];                        // rint(4096 * MI[r][c] * white[c]): white-normalised XYZ -> linear RGB
+    uint8_t inv[LAB_INV_N + 1];           // sat8(rint(255 * sRGB OETF(i / 4096)))
+    uint8_t pad_[3];
+};
+
+// Host builder (double precision, libm).  Same expressions, evaluated in the same order, as oracle/preproc.py lab_tables().
+static inline void lab_tables_build(LabTables* t, const uint8_t* lut256) {
+    static const double M[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+    static const double MI[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};
+    static const double WH[3] = {0.950456, 1.0, 1.088754};
+    for (int i = 0; i < 256; ++i) {
+        const double x = (double)i / 255.0;
+        const double l = x <= 0.04045 ? x / 12.92 : pow((x + 0.055) / 1.055, 2.4);
+        t->lin[i] = (uint16_t)rint(2040.0 * l);
+        const double L = (double)i * 100.0 / 255.0;
+        const double fy = (L + 16.0) / 116.0;
+        t->fy[i] = (uint16_t)rint(32768.0 * fy);
+        t->y[i] = (int32_t)rint(32768.0 * (L > 7.9996248 ? fy * fy * fy : L / 903.3));
+        t->at[i] = (int32_t)rint(32768.0 * (double)(i - 128) / 500.0);
+        t->bt[i] = (int32_t)rint(32768.0 * (double)(i - 128) / 200.0);
+        t->lut[i] = lut256[i];
+    }
+    for (int i = 0; i < LAB_CBRT_N; ++i) {
+        const double x = (double)i / 2040.0;
+        t->cbrt[i] = (uint16_t)rint(32768.0 * (x > 0.008856 ? cbrt(x) : 7.787 * x + 16.0 / 116.0));
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            t->c[r * 3 + c] = (int32_t)rint(4096.0 * M[r * 3 + c] / WH[r]);
+            t->ci[r * 3 + c] = (int32_t)rint(4096.0 * MI[r * 3 + c] * WH[c]);
+        }
+    for (int i = 0; i <= LAB_INV_N; ++i) {
+        const double x = (double)i / 4096.0;
+        const double v = rint(255.0 * (x <= 0.0031308 ? 12.92 * x : 1.055 * pow(x, 1.0 / 2.4) - 0.055));
+        t->inv[i] = (uint8_t)(v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v));
+    }
+    t->pad_[0] = t->pad_[1] = t->pad_[2] = 0;
+}
 
 struct UndistortParams {
     double ir[9];           // inverse camera matrix
@@ -19,13 +76,12 @@ struct UndistortParams {
 };
 
 #ifdef __HIPCC__
-__device__ __forceinline__ float pp_srgb_to_lin(float c) { return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f); }
-__device__ __forceinline__ float pp_lin_to_srgb(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f; }
-__device__ __forceinline__ float pp_lab_f(float t) { return t > 0.008856f ? cbrtf(t) : 7.787f * t + (float)(16.0 / 116.0); }
-__device__ __forceinline__ float pp_lab_finv(float t) { return t > 0.206893f ? t * t * t : (t - (float)(16.0 / 116.0)) / 7.787f; }
-__device__ __forceinline__ int pp_sat8(float v) {
-    const float r = rintf(v);
-    return r < 0.f ? 0 : (r > 255.f ? 255 : (int)r);
+__device__ __forceinline__ int pp_sat8i(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+// inverse of f() on a Q15 argument (may be negative): t > 0.206893 ? t^3 : (t - 16 / 116) / 7.787, Q15 result, floor rounding
+// of the shifted products like numpy's >> on int64
+__device__ __forceinline__ long long pp_lab_finv_q15(long long t) {
+    if (t >= 6780) return (t * t * t + (1ll << 29)) >> 30;
+    return ((t - 4520) * 269314 + (1ll << 20)) >> 21;          // 2^21 / 7.787 = 269 314.5; 16 / 116 in Q15 = 4519.7
 }
 
 // Source position of destination pixel (x, y) in 1/32 px: (sx, sy) integer part, (fx, fy) 5-bit fraction.
@@ -52,11 +108,10 @@ __device__ __forceinline__ void undistort_map_pixel(const UndistortParams& p, in
 
 // s: the frame [H][W][3] u8 (BGR); (x, y): destination pixel; out: its three channels.  map (optional): the camera's remap table
 // [H][W] of (sx, sy << 0 | fractions) built once by apse_set_camera with undistort_map_pixel -- the map depends on the camera
-// only, the f64 rational model per pixel was most of this function's time; lin (optional): srgb_to_lin of the 256 byte values,
-// built on the device with the same powf.
+// only, the f64 rational model per pixel was most of this function's time; lab: the Lab tables (device copy of LabTables).
 __device__ __forceinline__ void undistort_gamma_pixel(const UndistortParams& p, const uint8_t* __restrict__ s,
-                                                      const uint8_t* __restrict__ lut, int x, int y, int& c0, int& c1, int& c2,
-                                                      const int2* __restrict__ map = nullptr, const float* __restrict__ lin = nullptr) {
+                                                      const LabTables* __restrict__ lab, int x, int y, int& c0, int& c1, int& c2,
+                                                      const int2* __restrict__ map = nullptr) {
     if (p.do_undistort) {
         int sx, sy, fx, fy;
         if (map) {
@@ -81,25 +136,23 @@ __device__ __forceinline__ void undistort_gamma_pixel(const UndistortParams& p, 
     }
     if (p.do_gamma) {
         // channel 0 plays "R" (the reference converts a BGR frame with COLOR_RGB2LAB)
-        const float R = lin ? lin[c0] : pp_srgb_to_lin((float)c0 / 255.f), G = lin ? lin[c1] : pp_srgb_to_lin((float)c1 / 255.f),
-                    B = lin ? lin[c2] : pp_srgb_to_lin((float)c2 / 255.f);
-        const float X = (R * 0.412453f + G * 0.357580f + B * 0.180423f) / 0.950456f;
-        const float Y = R * 0.212671f + G * 0.715160f + B * 0.072169f;
-        const float Z = (R * 0.019334f + G * 0.119193f + B * 0.950227f) / 1.088754f;
-        const float fX = pp_lab_f(X), fY = pp_lab_f(Y), fZ = pp_lab_f(Z);
-        const float L = Y > 0.008856f ? 116.f * fY - 16.f : 903.3f * Y;
-        int L8 = pp_sat8(L * (float)(255.0 / 100.0));
-        const int a8 = pp_sat8(500.f * (fX - fY) + 128.f), b8 = pp_sat8(200.f * (fY - fZ) + 128.f);
-        L8 = lut[L8];
-        const float L2 = (float)L8 * (float)(100.0 / 255.0), a = (float)a8 - 128.f, bb = (float)b8 - 128.f;
-        const float fy_ = (L2 + 16.f) / 116.f, fx_ = fy_ + a / 500.f, fz_ = fy_ - bb / 200.f;
-        const float Y2 = L2 > 7.9996248f ? fy_ * fy_ * fy_ : L2 / 903.3f;
-        const float X2 = pp_lab_finv(fx_) * 0.950456f, Z2 = pp_lab_finv(fz_) * 1.088754f;
-        float r = X2 * 3.240479f + Y2 * -1.53715f + Z2 * -0.498535f;
-        float g = X2 * -0.969256f + Y2 * 1.875991f + Z2 * 0.041556f;
-        float bl = X2 * 0.055648f + Y2 * -0.204043f + Z2 * 1.057311f;
-        r = fminf(fmaxf(r, 0.f), 1.f); g = fminf(fmaxf(g, 0.f), 1.f); bl = fminf(fmaxf(bl, 0.f), 1.f);
-        c0 = pp_sat8(pp_lin_to_srgb(r) * 255.f); c1 = pp_sat8(pp_lin_to_srgb(g) * 255.f); c2 = pp_sat8(pp_lin_to_srgb(bl) * 255.f);
+        const int R = lab->lin[c0], G = lab->lin[c1], B = lab->lin[c2];
+        const int fX = lab->cbrt[(R * lab->c[0] + G * lab->c[1] + B * lab->c[2] + 2048) >> 12];
+        const int fY = lab->cbrt[(R * lab->c[3] + G * lab->c[4] + B * lab->c[5] + 2048) >> 12];
+        const int fZ = lab->cbrt[(R * lab->c[6] + G * lab->c[7] + B * lab->c[8] + 2048) >> 12];
+        const int L8 = pp_sat8i((296 * fY - 1336934 + 16384) >> 15);           // (116 fY - 16) * 255 / 100 in Q15: 296 = (116 * 255 + 50) / 100, 1336934 = (16 * 255 * 2^15 + 50) / 100
+        const int a8 = pp_sat8i((500 * (fX - fY) + (128 << 15) + 16384) >> 15);
+        const int b8 = pp_sat8i((200 * (fY - fZ) + (128 << 15) + 16384) >> 15);
+        const int L2 = lab->lut[L8];
+        const long long fy = lab->fy[L2];
+        const long long X = pp_lab_finv_q15(fy + lab->at[a8]), Y = lab->y[L2], Z = pp_lab_finv_q15(fy - lab->bt[b8]);
+        long long r = (X * lab->ci[0] + Y * lab->ci[1] + Z * lab->ci[2] + 16384) >> 15;
+        long long g = (X * lab->ci[3] + Y * lab->ci[4] + Z * lab->ci[5] + 16384) >> 15;
+        long long bl = (X * lab->ci[6] + Y * lab->ci[7] + Z * lab->ci[8] + 16384) >> 15;
+        r = r < 0 ? 0 : (r > LAB_INV_N ? LAB_INV_N : r);
+        g = g < 0 ? 0 : (g > LAB_INV_N ? LAB_INV_N : g);
+        bl = bl < 0 ? 0 : (bl > LAB_INV_N ? LAB_INV_N : bl);
+        c0 = lab->inv[r]; c1 = lab->inv[g]; c2 = lab->inv[bl];
     }
 }
 #endif

@@ -29,20 +29,17 @@ class FramePreprocessor:
         self.dist = np.ascontiguousarray(np.asarray(cam_params["dist"], np.float64).reshape(-1))
         self.lut_host = gamma_lut(gamma)
         self.undistort, self.gamma_correct = bool(undistort), bool(gamma_correct)
-        self._lut = None
 
     def __call__(self, frames):
         """frames: uint8 CUDA tensor [B, H, W, 3] (BGR) -> new tensor of the same shape."""
         if not frames.is_cuda:
             raise _lib.ApseError("FramePreprocessor needs CUDA frames (no CPU fallback)")
-        if self._lut is None or self._lut.device != frames.device:
-            self._lut = torch.from_numpy(self.lut_host).to(frames.device)
         frames = frames.contiguous()
         out = torch.empty_like(frames)
         B, H, W, _ = frames.shape
         rc = _lib.load().apse_undistort_gamma(
             _lib.ptr(frames), _lib.ptr(out), B, H, W, self.mtx.ctypes.data_as(C.POINTER(C.c_double)),
-            self.dist.ctypes.data_as(C.POINTER(C.c_double)), int(self.dist.size), _lib.ptr(self._lut), int(self.undistort),
+            self.dist.ctypes.data_as(C.POINTER(C.c_double)), int(self.dist.size), _lib.ptr(self.lut_host), int(self.undistort),
             int(self.gamma_correct), _lib.stream_ptr())
         _lib.check(rc, None, "apse_undistort_gamma")
         return out

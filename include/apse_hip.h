@@ -209,10 +209,16 @@ int apse_sqdist(const float* a_dev, const float* b_dev, int O, int N, int D, flo
 /* PIL resize + normalise as a stand-alone op (tables as in apse_set_resize_tables, device pointers). */
 /* preprocess_img (visualize_uav.py:56-71): cv2.undistort + Lab-L gamma on u8 BGR frames [B][H][W][3].
  * mtx3x3 row-major, dist up to 14 coefficients (k1 k2 p1 p2 k3 k4 k5 k6 s1..s4 tx ty; tilt must be 0),
- * lut256_dev = the 256-entry L-channel table on the device.  Either stage can be disabled. */
+ * lut256_host = the 256-entry L-channel table (HOST memory since round 3: the Lab step is integer arithmetic on tables derived
+ * from it on the host, see apse_lab_tables_host).  Either stage can be disabled. */
 int apse_undistort_gamma(const uint8_t* src_dev, uint8_t* dst_dev, int B, int H, int W, const double* mtx3x3_host,
-                         const double* dist_host, int ndist, const uint8_t* lut256_dev, int do_undistort, int do_gamma,
+                         const double* dist_host, int ndist, const uint8_t* lut256_host, int do_undistort, int do_gamma,
                          void* stream);
+/* Host only (no GPU touched): the integer tables of the Lab step (cvtColor RGB2LAB / LAB2RGB of visualize_uav.py:63-69 in the
+ * manner of OpenCV's 8-bit path; layout = struct LabTables of csrc/preproc_pixel.h) for a 256-entry L table, written to `out`.
+ * Returns the size of the block in bytes (call with out = NULL to query it).  tests/test_host_logic.py compares every entry
+ * with the oracle's numpy-built tables. */
+size_t apse_lab_tables_host(const uint8_t* lut256_host, void* out, size_t cap);
 int apse_resize_normalize(const uint8_t* frames_dev, uint8_t* tmp_dev, float* out_nhwc4_dev, uint8_t* resized_u8_dev,
                           const int* hb_dev, const int* hc_dev, int hk, const int* vb_dev, const int* vc_dev, int vk, int B,
                           int H, int W, int OH, int OW, int PH, int PW, const float* mean3_host, void* stream);

@@ -11,9 +11,19 @@ OpenCV is not installed and its source is not under /root/reference: **parity un
    matrix = mtx, tilt terms zero) + remap INTER_LINEAR on CV_16SC2 maps: coordinates rounded to 1/32 px
    (round-half-even), 15-bit integer bilinear weights (exact for 5-bit fractions), (sum + 2^14) >> 15,
    constant border 0.  Integer arithmetic after the map -> the HIP kernel matches this bit for bit.
- * Lab: the published CIE formulas OpenCV documents for 8-bit images (sRGB gamma, D65 white point,
-   L*255/100, a+128, b+128), evaluated in f32; OpenCV's own 8-bit path uses fixed-point tables whose
-   results can differ from this by +-1 level.
+ * Lab (round 3): integer and table-driven like the 8-bit path it stands in for (OpenCV 4.2 RGB2Lab_b /
+   Lab2RGBinteger): sRGB -> linear through a 256-entry table in 1/2040 units (gamma shift 3), a Q12 XYZ matrix
+   with rows divided by the D65 white point, a tabulated f() (cube root / linear toe) over that quantised value
+   in Q15, L / a / b descaled from Q15 with L scale (116*255+50)/100 and shift (16*255*2^15+50)/100 -- that much
+   is OpenCV's published structure -- then the way back: tabulated fy and Y per L byte, Q15 a / b offsets,
+   integer f^-1, a Q12 inverse matrix with the white point folded in, and a tabulated inverse gamma over a
+   12-bit linear value.  The published CIE constants (0.008856, 7.787, 903.3, sRGB 0.04045 / 12.92 / 2.4) are
+   the ones OpenCV documents; OpenCV's exact table contents and the shifts of its inverse path are NOT
+   reproducible here (cv2 absent, no fixture in the reference): parity with OpenCV itself stays unpinned.
+   What this buys: the HIP kernel (csrc/preproc_pixel.h) performs the same integer steps on tables built by
+   the same expressions, so HIP bytes == oracle bytes (tests/test_gpu_ops.py::test_undistort_gamma: 0 differ).
+   The f32-formula form of rounds 1-2 is kept as ``lab_gamma_f32`` (a cross-check of the integer design:
+   tests/test_oracle_golden.py bounds their difference).
 """
 import numpy as np
 
@@ -86,8 +96,67 @@ _MI = np.array([[3.240479, -1.53715, -0.498535], [-0.969256, 1.875991, 0.041556]
 _XN, _ZN = np.float32(0.950456), np.float32(1.088754)
 
 
+LAB_LIN_MAX, LAB_CBRT_N, LAB_INV_N = 2040, 3072, 4096
+_M64 = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]], np.float64)
+_MI64 = np.array([[3.240479, -1.53715, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]], np.float64)
+_WH64 = np.array([0.950456, 1.0, 1.088754], np.float64)
+
+
+def lab_tables(lut):
+    """The integer tables of the Lab step (float64 expressions, rounded half-to-even like C rint)."""
+    i = np.arange(256, dtype=np.float64)
+    x = i / 255.0
+    lin = np.where(x <= 0.04045, x / 12.92, np.power((x + 0.055) / 1.055, 2.4))
+    L = i * 100.0 / 255.0
+    fy = (L + 16.0) / 116.0
+    j = np.arange(LAB_CBRT_N, dtype=np.float64) / 2040.0
+    k = np.arange(LAB_INV_N + 1, dtype=np.float64) / 4096.0
+    inv = np.rint(255.0 * np.where(k <= 0.0031308, 12.92 * k, 1.055 * np.power(k, 1.0 / 2.4) - 0.055))
+    return dict(lin=np.rint(2040.0 * lin).astype(np.int64),
+                cbrt=np.rint(32768.0 * np.where(j > 0.008856, np.cbrt(j), 7.787 * j + 16.0 / 116.0)).astype(np.int64),
+                c=np.rint(4096.0 * _M64 / _WH64[:, None]).astype(np.int64),
+                lut=np.asarray(lut, np.int64),
+                fy=np.rint(32768.0 * fy).astype(np.int64),
+                y=np.rint(32768.0 * np.where(L > 7.9996248, fy * fy * fy, L / 903.3)).astype(np.int64),
+                at=np.rint(32768.0 * (i - 128.0) / 500.0).astype(np.int64),
+                bt=np.rint(32768.0 * (i - 128.0) / 200.0).astype(np.int64),
+                ci=np.rint(4096.0 * _MI64 * _WH64[None, :]).astype(np.int64),
+                inv=np.clip(inv, 0, 255).astype(np.int64))
+
+
+def _finv_q15(t):
+    """f^-1 on Q15 integers (may be negative): t > 0.206893 ? t^3 : (t - 16/116) / 7.787; >> is floor division."""
+    return np.where(t >= 6780, (t * t * t + (1 << 29)) >> 30, ((t - 4520) * 269314 + (1 << 20)) >> 21)
+
+
 def lab_gamma(img_u8, lut):
-    """RGB2LAB (8-bit convention) -> LUT on L -> LAB2RGB, f32 maths, channel 0 treated as R."""
+    """RGB2LAB (8-bit) -> LUT on L -> LAB2RGB in integer arithmetic on ``lab_tables``; channel 0 treated as R
+    (the reference converts a BGR frame with COLOR_RGB2LAB, visualize_uav.py:63)."""
+    T = lab_tables(lut)
+    src = img_u8.astype(np.int64)
+    R, G, B = T["lin"][src[..., 0]], T["lin"][src[..., 1]], T["lin"][src[..., 2]]
+    c = T["c"]
+    fX = T["cbrt"][(R * c[0, 0] + G * c[0, 1] + B * c[0, 2] + 2048) >> 12]
+    fY = T["cbrt"][(R * c[1, 0] + G * c[1, 1] + B * c[1, 2] + 2048) >> 12]
+    fZ = T["cbrt"][(R * c[2, 0] + G * c[2, 1] + B * c[2, 2] + 2048) >> 12]
+    L8 = np.clip((296 * fY - 1336934 + 16384) >> 15, 0, 255)
+    a8 = np.clip((500 * (fX - fY) + (128 << 15) + 16384) >> 15, 0, 255)
+    b8 = np.clip((200 * (fY - fZ) + (128 << 15) + 16384) >> 15, 0, 255)
+    L2 = T["lut"][L8]
+    fy = T["fy"][L2]
+    X = _finv_q15(fy + T["at"][a8])
+    Y = T["y"][L2]
+    Z = _finv_q15(fy - T["bt"][b8])
+    ci = T["ci"]
+    out = np.empty(img_u8.shape, np.uint8)
+    for ch in range(3):
+        v = (X * ci[ch, 0] + Y * ci[ch, 1] + Z * ci[ch, 2] + 16384) >> 15
+        out[..., ch] = T["inv"][np.clip(v, 0, LAB_INV_N)]
+    return out
+
+
+def lab_gamma_f32(img_u8, lut):
+    """The f32 CIE-formula form (rounds 1-2), kept as a cross-check of the integer design above."""
     f = np.float32
     c = img_u8.astype(np.float32) / f(255)
     lin = np.where(c <= f(0.04045), c / f(12.92), np.power((c + f(0.055)) / f(1.055), f(2.4))).astype(np.float32)

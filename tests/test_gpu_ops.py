@@ -586,8 +586,9 @@ def test_sqdist_and_normalize(logdir):
 
 
 def test_undistort_gamma(golden_dir, logdir):
-    """preprocess_img on the GPU vs oracle/preproc.py: the fixed-point undistort must be bit-exact; the f32
-    Lab gamma may differ by one level where powf/cbrtf round differently (parity vs OpenCV itself: unpinned)."""
+    """preprocess_img on the GPU vs oracle/preproc.py at 3840x2160: the fixed-point undistort AND the Lab gamma are integer
+    arithmetic on tables (round 3), so every byte must be equal -- stand-alone operator and on saturated random colours too.
+    Parity of either side with OpenCV itself: unpinned (cv2 absent; visualize_uav.py:62-69)."""
     from oracle import preproc as op
     from apse_uav_amd.utils.preprocess import FramePreprocessor
     with open(os.path.join(golden_dir, "cam_params.json")) as f:
@@ -595,19 +596,24 @@ def test_undistort_gamma(golden_dir, logdir):
     from apse_uav_amd.synthetic import SyntheticSequence
     frame = SyntheticSequence("static", 2160, 3840).frame(0)
     rng = np.random.default_rng(0)
-    frame[500:700, 900:1300] = rng.integers(0, 256, (200, 400, 3), dtype=np.uint8)      # high-frequency patch
+    frame[500:700, 900:1300] = rng.integers(0, 256, (200, 400, 3), dtype=np.uint8)      # high-frequency patch, every colour octant
     d = torch.from_numpy(frame).cuda()[None]
     und = FramePreprocessor(cam, undistort=True, gamma_correct=False)(d)[0].cpu().numpy()
     ref_u = op.undistort(frame, cam["mtx"], cam["dist"])
     nbad = int((und != ref_u).sum())
     full = FramePreprocessor(cam)(d)[0].cpu().numpy()
     ref_f = op.lab_gamma(ref_u, op.gamma_lut())
-    diff = np.abs(full.astype(np.int32) - ref_f.astype(np.int32))
-    _log(logdir, "preproc", dict(undistort_mismatch=nbad, gamma_max=int(diff.max()), gamma_frac=float((diff > 0).mean())))
+    gbad = int((full != ref_f).sum())
+    only_gamma = FramePreprocessor(cam, undistort=False, gamma_correct=True)(d)[0].cpu().numpy()
+    gbad2 = int((only_gamma != op.lab_gamma(frame, op.gamma_lut())).sum())
+    # all 2^24 colours through the Lab step (a 4096 x 4096 image)
+    v = np.arange(1 << 24, dtype=np.uint32)
+    cube = np.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    got_cube = FramePreprocessor(cam, undistort=False, gamma_correct=True)(torch.from_numpy(cube).cuda()[None])[0].cpu().numpy()
+    cbad = int((got_cube != op.lab_gamma(cube, op.gamma_lut())).sum())
+    _log(logdir, "preproc", dict(undistort_mismatch=nbad, gamma_mismatch=gbad, gamma_only_mismatch=gbad2, all_colours_mismatch=cbad))
     assert nbad == 0
-    # a one-level flip of the 8-bit L / a / b intermediates (powf/cbrtf ulp differences) is amplified by the
-    # gamma LUT and the inverse transform: rare pixels differ by a few levels
-    assert diff.max() <= 6 and (diff > 0).mean() < 1e-3
+    assert gbad == 0 and gbad2 == 0 and cbad == 0
     assert (full.astype(np.int32).mean() < frame.astype(np.int32).mean())                  # gamma 2 darkens
 
 

@@ -266,3 +266,55 @@ def test_model_zoo_pickle_is_refused(tmp_path):
     with pytest.raises(Exception) as ei:
         load_detector_file(str(p))
     assert "pickle" in str(ei.value).lower() or "weights_only" in str(ei.value).lower() or "unsupported" in str(ei.value).lower()
+
+
+def test_lab_tables_of_the_library_equal_the_oracles():
+    """The Lab step of preprocess_img (visualize_uav.py:62-69) is integer arithmetic on tables (csrc/preproc_pixel.h): the
+    library builds them on the host in C++ (libm, double), the oracle with numpy.  Every entry must agree -- this is what makes
+    the GPU bytes equal to the oracle's by construction; it runs on whatever host the tests run on (no GPU call)."""
+    import ctypes as C
+    from apse_uav_amd import _lib
+    from oracle import preproc as op
+
+    class LabTables(C.Structure):
+        _fields_ = [("lin", C.c_uint16 * 256), ("cbrt", C.c_uint16 * 3072), ("c", C.c_int32 * 9), ("lut", C.c_uint8 * 256),
+                    ("fy", C.c_uint16 * 256), ("y", C.c_int32 * 256), ("at", C.c_int32 * 256), ("bt", C.c_int32 * 256),
+                    ("ci", C.c_int32 * 9), ("inv", C.c_uint8 * 4097), ("pad_", C.c_uint8 * 3)]
+    lib = _lib.load()
+    for gamma in (2.0, 1.0, 0.5):
+        lut = op.gamma_lut(gamma)
+        t = LabTables()
+        assert lib.apse_lab_tables_host(_lib.ptr(lut), None, 0) == C.sizeof(LabTables)
+        assert lib.apse_lab_tables_host(_lib.ptr(lut), C.byref(t), C.sizeof(t)) == C.sizeof(LabTables)
+        ref = op.lab_tables(lut)
+        for name in ("lin", "cbrt", "lut", "fy", "y", "at", "bt", "inv"):
+            assert np.array_equal(np.asarray(getattr(t, name), np.int64), ref[name]), name
+        assert np.array_equal(np.asarray(t.c, np.int64).reshape(3, 3), ref["c"])
+        assert np.array_equal(np.asarray(t.ci, np.int64).reshape(3, 3), ref["ci"])
+    # table sanity: end points and monotonicity
+    assert ref["lin"][0] == 0 and ref["lin"][255] == 2040 and np.all(np.diff(ref["lin"]) >= 0)
+    assert ref["inv"][0] == 0 and ref["inv"][4096] == 255 and np.all(np.diff(ref["inv"]) >= 0)
+    assert ref["cbrt"][2040] == 32768 and np.all(np.diff(ref["cbrt"]) >= 0)
+
+
+def test_integer_lab_gamma_against_the_f32_formulas():
+    """The integer Lab step against the published CIE formulas in f32 (the form rounds 1-2 used): they must describe the same
+    transform -- identity LUT returns the input up to the 8-bit Lab quantisation, gamma 2 agrees within that quantisation."""
+    from oracle import preproc as op
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (256, 384, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:256, 0:384]
+    smooth = np.stack([xx * 255 // 383, yy, (xx + yy) * 255 // 638], -1).astype(np.uint8)
+    for im in (img, smooth):
+        a = op.lab_gamma(im, op.gamma_lut()).astype(np.int32)
+        b = op.lab_gamma_f32(im, op.gamma_lut()).astype(np.int32)
+        d = np.abs(a - b)
+        assert d.mean() < 0.5 and (d > 2).mean() < 0.04, (d.mean(), (d > 2).mean(), d.max())
+        ident = np.arange(256, dtype=np.uint8)
+        ri = np.abs(op.lab_gamma(im, ident).astype(np.int32) - im.astype(np.int32))
+        rf = np.abs(op.lab_gamma_f32(im, ident).astype(np.int32) - im.astype(np.int32))
+        assert ri.mean() < rf.mean() + 0.25, (ri.mean(), rf.mean())         # no worse a round trip than the f32 form's
+    grey = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)
+    out = op.lab_gamma(grey, op.gamma_lut())
+    assert np.all(np.diff(out[0, :, 0].astype(np.int32)) >= 0) and out[0, 255, 0] >= 254 and out[0, 0, 0] == 0      # grey ramp stays monotone
+    assert np.abs(out[..., 0].astype(np.int32) - out[..., 1]).max() <= 1 and np.abs(out[..., 1].astype(np.int32) - out[..., 2]).max() <= 1

@@ -7,13 +7,13 @@ tag=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --throughput-depth 0 --no-entrypoint "$@" > $O/${tag}_bench.json 2> $O/prof_$tag.err || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --throughput-depth 0 --no-entrypoint --no-extra-modes "$@" > $O/${tag}_bench.json 2> $O/prof_$tag.err || exit 2
 cp $(find $O/prof_$tag -name "*kernel_stats.csv" | head -1) $O/${tag}_kernel_stats.csv
 rm -rf $O/prof_$tag
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc_${c}_$tag -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events --throughput-depth 0 --no-entrypoint "$@" > /dev/null 2> $O/pmc_${c}_$tag.err || exit 3
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_${c}_$tag -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events --throughput-depth 0 --no-entrypoint --no-extra-modes "$@" > /dev/null 2> $O/pmc_${c}_$tag.err || exit 3
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma_$tag -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events --throughput-depth 0 --no-entrypoint "$@" > /dev/null 2> $O/pmc_mfma_$tag.err || exit 4
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma_$tag -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events --throughput-depth 0 --no-entrypoint --no-extra-modes "$@" > /dev/null 2> $O/pmc_mfma_$tag.err || exit 4
 cd $R
 python tools/pmc_summary.py $O/pmc_FETCH_SIZE_$tag $O/pmc_WRITE_SIZE_$tag $O/${tag}_pmc_traffic.json > $O/${tag}_pmc_traffic.txt 2>&1
 python tools/pmc_mfma.py $O/pmc_mfma_$tag > $O/${tag}_pmc_mfma_util.txt 2>&1

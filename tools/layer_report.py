@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Per-layer convolution efficiency from a rocprofv3 --kernel-trace CSV of bench.py (last frame)."""
+"""Per-layer convolution efficiency from a rocprofv3 --kernel-trace CSV of bench.py (last step).
+usage: layer_report.py <kernel_trace.csv> [detections per FRAME] [batch]      (M, FLOPs and TFLOP/s are those of the whole batch)"""
 import collections
 import csv
 import sys
 
 path = sys.argv[1]
 ndet = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+BATCH = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+ndet *= BATCH                      # the packed detection list of a step holds every image's detections
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'pil_resize_h' in r['Kernel_Name'].split('(')[0]]
@@ -13,11 +16,12 @@ fr = rows[idx[-2]:idx[-1]]
 t0 = int(fr[0]['Start_Timestamp'])
 span = (int(fr[-1]['End_Timestamp']) - t0) / 1e3
 busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in fr) / 1e3
-print('frame: %d kernels, span %.1f us, busy %.1f us' % (len(fr), span, busy))
+print('step (batch %d): %d kernels, span %.1f us, busy %.1f us' % (BATCH, len(fr), span, busy))
 layers = []
 
 
-def conv(name, M, Cout, K):
+def conv(name, M, Cout, K, per_image=True):
+    M = M * BATCH if per_image else M
     layers.append((name, M, Cout, K, 2.0 * M * Cout * K))
 
 
@@ -49,10 +53,10 @@ conv('fc1', 1000, 1024, 12544)
 conv('fc2', 1000, 1024, 1024)
 conv('pred', 1000, 21, 1024)
 for i in range(4):
-    conv('mask%d' % i, ndet * 196, 256, 2304)
-conv('deconv', ndet * 196, 1024, 256)
-conv('mlogit', ndet * 784, 4, 256)
-conv('assoc', ndet, 128, 25600)
+    conv('mask%d' % i, ndet * 196, 256, 2304, False)
+conv('deconv', ndet * 196, 1024, 256, False)
+conv('mlogit', ndet * 784, 4, 256, False)
+conv('assoc', ndet, 128, 25600, False)
 # attribute split-K reduce kernels to the preceding conv
 items = []
 for r in fr:
