@@ -47,7 +47,6 @@ struct ConvParams {
     int prec;             // 0: exact f32 MFMA; 1 / 2: bf16 / f16 operands (rounded at LDS staging unless stored so), f32 accumulate
     int x_st, res_st, y_st;   // storage type of x / res / y: 0 f32, 1 bf16, 2 f16 (pointers are then 16-bit element arrays)
     int no_stream;            // 1: keep this launch on the tiled kernel (a caller forcing a tile shape: tests, sweeps)
-    int stream_k;             // 1: a 1x1 layer of any K may take the streamed-A kernel (planner: enough rows to fill the chip)
 };
 
 // cfg: 0=128x128 1=64x64 2=128x32 3=128x64.  ev0/ev1 (optional) are recorded right before / after the
@@ -57,20 +56,18 @@ int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk);
 int apse_launch_conv_bf16(const ConvParams& p, int cfg, hipStream_t s);   // conv_igemm_bf16.hip
 // conv1x1_stream.hip: the memory-streaming kernel for small-K / wide-N 1x1 layers (cfg label APSE_CFG_STREAM in profiles)
 #define APSE_CFG_STREAM 9
-#define APSE_CFG_STREAM_K 10
+// (label 10 was conv1x1_stream_k, the streamed-A variant for K > 256: measured slower than the tiled kernel in round 2, removed in round 3)
 #define APSE_CFG_GLDS 11             // conv_glds16.hip: 256x128 tile, 16-bit operands, LDS-DMA ring
 #define APSE_CFG_STEMPOOL 12         // stem_pool16.hip: stem convolution + ReLU + max-pool of the 16-bit modes (profile label only)
 #define APSE_CFG_SKINNY 13           // conv_skinny.hip: <= 16 output channels over K = 256, activations straight into 16x16x4 MFMAs (RPN head, mask predictor)
 #define APSE_NCFG 14
 bool apse_conv1x1_stream_ok(const ConvParams& p);
 int apse_launch_conv1x1_stream(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-bool apse_conv1x1_stream_k_ok(const ConvParams& p);
-int apse_launch_conv1x1_stream_k(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 bool apse_conv_glds16_ok(const ConvParams& p);
 bool apse_conv_skinny_ok(const ConvParams& p);
 int apse_launch_conv_skinny(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int apse_launch_conv_glds16(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-// which kernel apse_launch_conv runs for (p, cfg): APSE_CFG_STREAM / APSE_CFG_STREAM_K, or cfg itself (a tiled shape)
+// which kernel apse_launch_conv runs for (p, cfg): a special kernel's label (APSE_CFG_STREAM, ...), or cfg itself (a tiled shape)
 int apse_conv_effective_cfg(const ConvParams& p, int cfg);
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 

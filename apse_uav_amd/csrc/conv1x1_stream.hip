@@ -230,231 +230,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
     }
 }
 
-// ------------------------------------------------------------------------------------------------ any K: A streamed
-// Same block shape and epilogue for the 1x1 layers whose K does not fit in registers (the "reduction" convs conv1 of every
-// bottleneck, K = 4 x N; laterals 3..5; the res5 expansions): the wave's 32-row A strip is streamed stage by stage straight
-// into MFMA operand registers, D stages ahead (a ring of D register sets, indices static through a D-fold unrolled loop).
-// NT n tiles of 32 columns per chunk: 8 (all of N = 256 in one pass: every activation byte is read ONCE) or 4; with
-// N > 32 NT the strip is re-streamed per chunk (L2 / Infinity-Cache hits: a block's strip is <= 512 KB).
-template <int PR, int NT, int D>
-__global__ __launch_bounds__(256, NT >= 8 ? 1 : 2) void conv1x1_stream_k(const ConvParams p, const int chunks_per_block) {
-    constexpr int ESH = PR ? 1 : 2;
-    constexpr int KSTEP = PR ? 64 : 32;
-    constexpr int EPSLOT = 16 >> ESH;
-    constexpr int NC = 32 * NT;
-    constexpr int CLD = 68;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ws = smem;                                            // [2][NC][128 B]
-    float* Cw = reinterpret_cast<float*>(smem + 2 * NC * 128);  // [4 waves][32][CLD]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 31, fh = lane >> 5;
-    const int srow = tid >> 3, slot = tid & 7;
-    const int M = p.M, N = p.Cout;
-    const int m0 = blockIdx.x * 128 + wave * 32;
-    const int chunks_total = N / NC;
-    const int c_begin = blockIdx.y * chunks_per_block;
-    const int c_end = (c_begin + chunks_per_block < chunks_total) ? c_begin + chunks_per_block : chunks_total;
-    if (c_begin >= c_end) return;
-    const int ohw = p.OH * p.OW;
-    const int nst = p.KWCp / KSTEP;                             // k stages per chunk (runtime)
-    const int T = (c_end - c_begin) * nst;                      // stages of this block
-
-    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0,
-                                                                    (int)(((unsigned)(p.B * p.H * p.W) << p.cin_log2) << ESH), 0x00020000);
-    unsigned abase = 0xfffffff0u;
-    {
-        const int m = m0 + fr;
-        if (m < M) {
-            int pix = m;
-            if (p.stride != 1) {
-                const int b = m / ohw, rem = m - b * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
-                pix = (b * p.H + oy * p.stride) * p.W + ox * p.stride;
-            }
-            abase = (((unsigned)pix << p.cin_log2) << ESH) + (unsigned)((fh * EPSLOT) << ESH);
-        }
-    }
-    const bool arow = abase != 0xfffffff0u;
-    f32x4 a[D][4];
-    int a_s = 0;                                                // k stage (within the chunk) of the next A fetch
-    int a_t = 0;                                                // global stage index of the next A fetch
-    auto a_fetch = [&](int set) {
-        const bool live = arow && a_t < T;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const unsigned off = live ? abase + (unsigned)((a_s * KSTEP + 2 * c * EPSLOT) << ESH) : 0xfffffff0u;
-            a[set][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
-        }
-        ++a_t;
-        if (++a_s == nst) a_s = 0;
-    };
-
-    const char* wbase = (PR ? reinterpret_cast<const char*>(p.w16) : reinterpret_cast<const char*>(p.w)) + ((size_t)(slot * EPSLOT) << ESH);
-    f32x4 wr[NT];
-    int w_s = 0, w_ch = c_begin;                                // (chunk, stage) of the next filter fetch
-    auto w_fetch = [&]() {
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const size_t n = (size_t)w_ch * NC + srow + 32 * i;
-            wr[i] = *reinterpret_cast<const f32x4*>(wbase + ((n * (size_t)p.KWCp + (size_t)w_s * KSTEP) << ESH));
-        }
-        if (++w_s == nst) { w_s = 0; ++w_ch; }
-    };
-    auto w_store = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int row = srow + 32 * i;
-            *reinterpret_cast<f32x4*>(Ws + buf * NC * 128 + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = wr[i];
-        }
-    };
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d) a_fetch(d);                 // stages 0 .. D-2 in flight
-    w_fetch();
-    w_store(0);
-    if (T > 1) w_fetch();
-    __syncthreads();
-
-    float* cw = Cw + wave * 32 * CLD;
-    const int erow = lane >> 3, ecol = (lane & 7) * 8;
-    f32x16 acc[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
-    int s_in_chunk = 0, ch = c_begin;
-    for (int t0 = 0; t0 < T; t0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int t = t0 + d;
-            if (t < T) {
-                const int buf = t & 1;
-                if (t + 1 < T) w_store(buf ^ 1);
-                if (t + 2 < T) w_fetch();
-                a_fetch((d + D - 1) % D);                       // stage t + D - 1 (zeros past the end)
-                const char* Wb = Ws + buf * NC * 128;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int ls = 2 * c + fh;
-#pragma unroll
-                    for (int j0 = 0; j0 < NT; j0 += 4) {
-                        f32x4 bfr[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int row = (j0 + j) * 32 + fr;
-                            bfr[j] = *reinterpret_cast<const f32x4*>(Wb + row * 128 + ((ls ^ ((row >> 1) & 7)) << 4));
-                        }
-                        if constexpr (PR != 0) {
-                            typedef typename std::conditional<PR == 1, bf16x8, f16x8>::type op8;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                acc[j0 + j] = s1_mfma16(__builtin_bit_cast(op8, a[d][c]), __builtin_bit_cast(op8, bfr[j]), acc[j0 + j]);
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    acc[j0 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][c][k], bfr[j][k], acc[j0 + j], 0, 0, 0);
-                        }
-                    }
-                }
-                __syncthreads();
-                if (++s_in_chunk == nst) {
-                    // ---- chunk epilogue (wave-private), NT / 2 passes of 64 columns
-                    s_in_chunk = 0;
-                    const int n0 = ch * NC;
-                    ++ch;
-#pragma unroll
-                    for (int hh = 0; hh < NT / 2; ++hh) {
-                        const int nb = n0 + hh * 64 + ecol;
-                        constexpr int RV = PR ? 1 : 2;
-                        f32x4 rr[4][RV];
-                        if (p.res_mode != 0) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int m = m0 + erow + 8 * i;
-#pragma unroll
-                                for (int q = 0; q < RV; ++q) rr[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                                if (m < M) {
-                                    size_t ridx;
-                                    if (p.res_mode == 1) ridx = (size_t)m * N + nb;
-                                    else {
-                                        const int b = m / ohw, rem = m - b * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
-                                        ridx = ((size_t)b * ((p.OH >> 1) * (p.OW >> 1)) + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * N + nb;
-                                    }
-                                    if constexpr (PR == 0) {
-                                        rr[i][0] = *reinterpret_cast<const f32x4*>(p.res + ridx);
-                                        rr[i][RV - 1] = *reinterpret_cast<const f32x4*>(p.res + ridx + 4);
-                                    } else {
-                                        rr[i][0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint16_t*>(p.res) + ridx);
-                                    }
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                            for (int v = 0; v < 16; ++v) {
-                                cw[((v & 3) + 8 * (v >> 2) + 4 * fh) * CLD + jj * 32 + fr] = acc[2 * hh + jj][v];
-                                acc[2 * hh + jj][v] = 0.f;
-                            }
-                        __builtin_amdgcn_wave_barrier();
-                        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-                        if (p.bias) {
-                            b0 = *reinterpret_cast<const f32x4*>(p.bias + nb);
-                            b1 = *reinterpret_cast<const f32x4*>(p.bias + nb + 4);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int r = erow + 8 * i, m = m0 + r;
-                            f32x4 v0 = *reinterpret_cast<const f32x4*>(cw + r * CLD + ecol) + b0;
-                            f32x4 v1 = *reinterpret_cast<const f32x4*>(cw + r * CLD + ecol + 4) + b1;
-                            if (p.res_mode != 0) {
-                                if constexpr (PR == 0) { v0 += rr[i][0]; v1 += rr[i][RV - 1]; }
-                                else {
-                                    const f32x4 raw = rr[i][0];
-                                    f32x4 x0, x1;
-                                    if constexpr (PR == 1) {
-                                        const unsigned q0 = __float_as_uint(raw[0]), q1 = __float_as_uint(raw[1]), q2 = __float_as_uint(raw[2]), q3 = __float_as_uint(raw[3]);
-                                        x0 = f32x4{__uint_as_float(q0 << 16), __uint_as_float(q0 & 0xffff0000u), __uint_as_float(q1 << 16), __uint_as_float(q1 & 0xffff0000u)};
-                                        x1 = f32x4{__uint_as_float(q2 << 16), __uint_as_float(q2 & 0xffff0000u), __uint_as_float(q3 << 16), __uint_as_float(q3 & 0xffff0000u)};
-                                    } else {
-                                        const f16x8 hv = __builtin_bit_cast(f16x8, raw);
-                                        x0 = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
-                                        x1 = f32x4{(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
-                                    }
-                                    v0 += x0; v1 += x1;
-                                }
-                            }
-                            if (p.relu) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) { v0[k] = v0[k] > 0.f ? v0[k] : 0.f; v1[k] = v1[k] > 0.f ? v1[k] : 0.f; }
-                            }
-                            if (m < M) {
-                                const size_t yi = (size_t)m * N + nb;
-                                if constexpr (PR == 0) {
-                                    APSE_NT_STORE(v0, reinterpret_cast<f32x4*>(p.y + yi));
-                                    APSE_NT_STORE(v1, reinterpret_cast<f32x4*>(p.y + yi + 4));
-                                } else if constexpr (PR == 1) {
-                                    bf16x8 o;
-                                    o[0] = (__bf16)v0[0]; o[1] = (__bf16)v0[1]; o[2] = (__bf16)v0[2]; o[3] = (__bf16)v0[3];
-                                    o[4] = (__bf16)v1[0]; o[5] = (__bf16)v1[1]; o[6] = (__bf16)v1[2]; o[7] = (__bf16)v1[3];
-                                    APSE_NT_STORE(o, reinterpret_cast<bf16x8*>(reinterpret_cast<uint16_t*>(p.y) + yi));
-                                } else {
-                                    f16x8 o;
-                                    o[0] = (_Float16)v0[0]; o[1] = (_Float16)v0[1]; o[2] = (_Float16)v0[2]; o[3] = (_Float16)v0[3];
-                                    o[4] = (_Float16)v1[0]; o[5] = (_Float16)v1[1]; o[6] = (_Float16)v1[2]; o[7] = (_Float16)v1[3];
-                                    APSE_NT_STORE(o, reinterpret_cast<f16x8*>(reinterpret_cast<uint16_t*>(p.y) + yi));
-                                }
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ dispatch
 // Eligible: 1x1, pad 0, stride 1 or 2, NHWC rows of exactly K = 64 / 128 / 256 channels, N a multiple of 128, plain NHWC
 // output (no deconv scatter, no channel offset), unsplit, not count-limited.  16-bit: activations stored in the operand
@@ -496,48 +271,6 @@ static int launch_stream(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hip
     hipLaunchKernelGGL((conv1x1_stream<PR, KA>), dim3(mblocks, (chunks + per - 1) / per), dim3(256), lds, s, p, per);
     if (ev1) hipEventRecord(ev1, s);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
-}
-
-// ---- streamed-A variant: any K that is a whole number of stages; N a multiple of 128.  Shape eligibility only: whether a
-// layer USES it is the planner's decision (ConvParams.stream_k, from the layer's full-batch M: it needs >= ~1 block per CU).
-bool apse_conv1x1_stream_k_ok(const ConvParams& p) {
-    static const bool off = getenv("APSE_NO_STREAM1X1") != nullptr;
-    if (off || p.no_stream) return false;
-    const int K = 1 << p.cin_log2;
-    if (p.KH != 1 || p.KW != 1 || p.pad != 0 || (p.stride != 1 && p.stride != 2)) return false;
-    if (p.KWCp != K || K < 64 || (p.Cout & 127) != 0) return false;
-    if (p.out_mode != 0 || p.y_coff != 0 || p.y_ld != p.Cout || p.splitk != 1 || p.m_count || p.tile_cnt) return false;
-    if ((((size_t)p.B * p.H * p.W) << p.cin_log2) * (p.prec ? 2 : 4) >= 0xfffffff0ull) return false;
-    if (p.y_st != p.prec || (p.res_mode != 0 && p.res_st != p.prec)) return false;
-    if (p.prec == 0) return false;                                            // 16-bit modes only (f32: see DESIGN.md)
-    return p.x_st == p.prec && p.w16 != nullptr;
-}
-
-template <int PR, int NT, int D>
-static int launch_stream_k(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    const size_t lds = 2 * (32 * NT) * 128 + 4 * 32 * 68 * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_k<PR, NT, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    const int mblocks = (p.M + 127) / 128, chunks = p.Cout / (32 * NT);
-    int ysplit = 1;
-    while (mblocks * ysplit < 512 && ysplit < chunks) ysplit *= 2;
-    if (ysplit > chunks) ysplit = chunks;
-    const int per = (chunks + ysplit - 1) / ysplit;
-    if (ev0) hipEventRecord(ev0, s);
-    hipLaunchKernelGGL((conv1x1_stream_k<PR, NT, D>), dim3(mblocks, (chunks + per - 1) / per), dim3(256), lds, s, p, per);
-    if (ev1) hipEventRecord(ev1, s);
-    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
-}
-
-int apse_launch_conv1x1_stream_k(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    const bool wide = (p.Cout & 255) == 0;                                    // 8 n tiles per chunk: N = 256 in ONE pass over A
-    // 8 tiles: 128 accumulator registers -> one wave per SIMD, which in turn affords a 5-deep A ring (20 KB in flight per wave)
-    static const bool narrow_only = getenv("APSE_STREAMK_NT4") != nullptr;   // sweeps: force the 4-tile variant
-    if (wide && !narrow_only) return p.prec == 1 ? launch_stream_k<1, 8, 5>(p, s, ev0, ev1) : launch_stream_k<2, 8, 5>(p, s, ev0, ev1);
-    return p.prec == 1 ? launch_stream_k<1, 4, 3>(p, s, ev0, ev1) : launch_stream_k<2, 4, 3>(p, s, ev0, ev1);
 }
 
 int apse_launch_conv1x1_stream(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {

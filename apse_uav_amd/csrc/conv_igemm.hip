@@ -684,14 +684,10 @@ int apse_conv_effective_cfg(const ConvParams& p, int cfg) {
     // an explicit request for a special kernel is honoured only when the layer is eligible (-1 otherwise: an error, never a
     // silent launch on a shape the kernel does not handle)
     if (cfg == APSE_CFG_STREAM) return (!p.no_stream && apse_conv1x1_stream_ok(p)) ? APSE_CFG_STREAM : -1;
-    if (cfg == APSE_CFG_STREAM_K) return (!p.no_stream && apse_conv1x1_stream_k_ok(p)) ? APSE_CFG_STREAM_K : -1;
     if (cfg == APSE_CFG_GLDS) return apse_conv_glds16_ok(p) ? APSE_CFG_GLDS : -1;
     if (cfg == APSE_CFG_SKINNY) return apse_conv_skinny_ok(p) ? APSE_CFG_SKINNY : -1;
     if (!p.no_stream && apse_conv_skinny_ok(p)) return APSE_CFG_SKINNY;
-    if (!p.no_stream) {
-        if (apse_conv1x1_stream_ok(p)) return APSE_CFG_STREAM;
-        if (p.stream_k && apse_conv1x1_stream_k_ok(p)) return APSE_CFG_STREAM_K;
-    }
+    if (!p.no_stream && apse_conv1x1_stream_ok(p)) return APSE_CFG_STREAM;
     // wherever the 16-bit path would take the register-staged 256x128 tile, the LDS-DMA kernel of the same tile runs instead
     if (!p.no_stream && fast16_shape(p, cfg) == 8 && apse_conv_glds16_ok(p)) return APSE_CFG_GLDS;     // (a caller forcing cfg 8 keeps the register-staged tile)
     return cfg;
@@ -703,7 +699,6 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0
     const int eff = apse_conv_effective_cfg(p, cfg);
     if (eff < 0) return APSE_E_INVALID;                                   // a streaming kernel asked for, layer not eligible
     if (eff == APSE_CFG_STREAM) return apse_launch_conv1x1_stream(p, s, ev0, ev1);
-    if (eff == APSE_CFG_STREAM_K) return apse_launch_conv1x1_stream_k(p, s, ev0, ev1);
     if (eff == APSE_CFG_GLDS) return apse_launch_conv_glds16(p, s, ev0, ev1);
     if (eff == APSE_CFG_SKINNY) return apse_launch_conv_skinny(p, s, ev0, ev1);
     if (p.prec == 1 || p.prec == 2) {

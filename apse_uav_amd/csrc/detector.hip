@@ -345,8 +345,6 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     const int Mfull = c->cfg.max_batch * in_items_mult * p.OH * p.OW;
     int sk = 1;
     cs.cfg = apse_conv_pick_cfg(Mfull, Cout, p.steps_total, &sk);
-    // 1x1 layers of K > 256: the streamed-A kernel (conv1x1_stream_k) does not beat the tiled kernel yet: off
-    p.stream_k = 0;
     if (count_kind == 2) {
         // GEMMs over the packed detection list: the tile shape and the K split fix the f32 summation order, so they are
         // chosen HERE, once, from plan constants only (a typical list of APSE_EXPECTED_DETS detections per image of the
@@ -1194,12 +1192,11 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
     if (p.x_st && cin_p < 8) return APSE_E_INVALID;
     int sk = 1;
     int cfg = apse_conv_pick_cfg(p.M, p.Cout, p.steps_total, &sk);
-    if (d->cfg >= 0) { cfg = d->cfg; sk = 1; p.no_stream = (d->cfg != APSE_CFG_STREAM && d->cfg != APSE_CFG_STREAM_K && d->cfg != APSE_CFG_GLDS && d->cfg != APSE_CFG_SKINNY); }
+    if (d->cfg >= 0) { cfg = d->cfg; sk = 1; p.no_stream = (d->cfg != APSE_CFG_STREAM && d->cfg != APSE_CFG_GLDS && d->cfg != APSE_CFG_SKINNY); }
     if (d->splitk > 0) sk = d->splitk;
     if (sk > p.steps_total) sk = p.steps_total;
     p.splitk = sk;
     if (sk > 1 && (size_t)sk * p.M * p.Cout * sizeof(float) > ws_bytes) return APSE_E_INVALID;
-    p.stream_k = 0;
     if (sk > 1 && d->fuse_reduce) {
         static int* cnt = nullptr;
         if (!cnt) { if (hipMalloc(reinterpret_cast<void**>(&cnt), 65536 * sizeof(int)) != hipSuccess) return APSE_E_NOMEM; hipMemset(cnt, 0, 65536 * sizeof(int)); }

@@ -345,6 +345,9 @@ def test_config3_like_batch4_bf16_with_preproc(setup, logdir, golden_dir):
         n, rn = len(inst), int(post["boxes"].shape[0])
         from hip_helpers import explain_frame
         rep, unexplained = explain_frame(tr.predictor.model, post, b=b)
+        _log(logdir, "config3/img%d" % b, dict(n=n, ref_n=rn, matched=rep["box"]["matched"], only=rep["box"]["only"], unexplained=unexplained,
+                                                noise_q999_logit=rep["box"]["score_noise_q999"], noise_rms_logit=rep["box"]["score_noise_rms"],
+                                                noise_largest=rep["box"]["score_noise_largest"]))
         assert not unexplained, (b, unexplained)       # every difference of the kept sets sits inside the measured bf16 noise of a decision
         tot += n
         matched += rep["box"]["matched"]
