@@ -56,7 +56,7 @@ int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk);
 int apse_launch_conv_bf16(const ConvParams& p, int cfg, hipStream_t s);   // conv_igemm_bf16.hip
 // conv1x1_stream.hip: the memory-streaming kernel for small-K / wide-N 1x1 layers (cfg label APSE_CFG_STREAM in profiles)
 #define APSE_CFG_STREAM 9
-// (label 10 was conv1x1_stream_k, the streamed-A variant for K > 256: measured slower than the tiled kernel in round 2, removed in round 3)
+#define APSE_CFG_BNECK 10            // bottleneck16.hip: a whole 64-channel bottleneck (conv1 + conv2 + conv3 + residual) in one launch (profile label only)
 #define APSE_CFG_GLDS 11             // conv_glds16.hip: 256x128 tile, 16-bit operands, LDS-DMA ring
 #define APSE_CFG_STEMPOOL 12         // stem_pool16.hip: stem convolution + ReLU + max-pool of the 16-bit modes (profile label only)
 #define APSE_CFG_SKINNY 13           // conv_skinny.hip: <= 16 output channels over K = 256, activations straight into 16x16x4 MFMAs (RPN head, mask predictor)

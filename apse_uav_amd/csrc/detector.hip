@@ -33,6 +33,8 @@ bool apse_assoc_fc_ok(int K, int N);
 int apse_k_assoc_fc(const float*, const float*, const float*, float*, const int*, int, int, int, float*, float*, hipStream_t);
 int apse_k_stem_pool16(const void*, const uint16_t*, const float*, void*, int, int, int, int, hipStream_t, hipEvent_t, hipEvent_t);
 int apse_k_subsample2(const void*, void*, int, int, int, int, int, hipStream_t);
+int apse_k_bottleneck64_fused16(const void*, const void*, void*, const uint16_t*, const float*, const uint16_t*, const float*,
+                                const uint16_t*, const float*, int, int, int, int, int, hipStream_t, hipEvent_t, hipEvent_t);
 int apse_k_nhwc_to_nchw(const void*, float*, int, int, int, int, hipStream_t);
 int apse_k_rpn_topk_stage(const RpnLevels*, const TopkJob*, int, uint64_t*, int, int, uint32_t*, hipStream_t);
 int apse_k_rpn_decode(const RpnLevels*, int, const uint64_t*, int, const int*, float, float, float, float*, float*, int*,
@@ -79,8 +81,9 @@ struct ConvStep {
     void* pool_y = nullptr;   // != nullptr: the stem of the 16-bit modes, run as stem_s2d_pool16 (conv + ReLU + 3x3/2 max-pool) into this map
     std::string name;
 };
-enum StepKind { S_CONV, S_MAXPOOL, S_SUBSAMPLE };
-struct Step { StepKind kind; ConvStep c; const float* x; float* y; int H, W, C; int st = 0; };
+enum StepKind { S_CONV, S_MAXPOOL, S_SUBSAMPLE, S_BNECK };
+// S_BNECK: a whole 64-channel bottleneck as one launch (bottleneck16.hip); c = its conv1 (name, flops of all three), c2 / c3 the others
+struct Step { StepKind kind; ConvStep c; const float* x; float* y; int H, W, C; int st = 0; ConvParams p2, p3; };
 
 struct apse_ctx {
     apse_config cfg;
@@ -420,6 +423,18 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
                 cfg = apse_conv_effective_cfg(p, cfg);                        // profile label of the kernel that actually ran
             }
             if (e0 >= 0) c->pending.push_back({cfg, st.c.flops_per_item, st.c.count_kind, st.c.b_mult, batch, e0, e0 + 1});
+        } else if (st.kind == S_BNECK) {
+            int e0 = -1;
+            if (c->prof_on && c->ev_used == 0) {
+                hipEventRecord(c->ev_pool[0], s);
+                hipEventRecord(c->ev_pool[1], s);
+                c->ev_used = 2;
+            }
+            if (c->prof_on && c->ev_used + 2 <= (int)c->ev_pool.size()) { e0 = c->ev_used; c->ev_used += 2; }
+            const ConvParams& q1 = st.c.p;
+            rc = apse_k_bottleneck64_fused16(st.x, st.p3.res, st.y, q1.w16, q1.bias, st.p2.w16, st.p2.bias, st.p3.w16, st.p3.bias, batch,
+                                             st.H, st.W, st.C, st.st, s, e0 >= 0 ? c->ev_pool[e0] : nullptr, e0 >= 0 ? c->ev_pool[e0 + 1] : nullptr);
+            if (e0 >= 0) c->pending.push_back({APSE_CFG_BNECK, st.c.flops_per_item, 0, 1, batch, e0, e0 + 1});
         } else if (st.kind == S_MAXPOOL) {
             rc = apse_k_maxpool3x3s2(st.x, st.y, batch, st.H, st.W, st.C, st.st, s);
         } else {
@@ -522,6 +537,28 @@ static int build_plan(apse_ctx* c) {
             rc = add_conv(c, c->backbone, ConvSpec{P + ".conv3", {P + ".conv3"}, 1, 1, 1, 0, 1}, b2, 1, &out,
                           last ? std::string(stage) : P + ".out", resp, 1, 0, 0);
             if (rc) return rc;
+            // 16-bit storage modes, 64 mid channels (res2): conv1 -> conv2 -> conv3 + residual as ONE launch with the two
+            // 64-channel intermediates in LDS (bottleneck16.hip; same bits as the three launches).  APSE_NO_BNECK_FUSE (read when
+            // the context is built) keeps the three-kernel form, for the equality test and A/B runs.
+            {
+                const size_t n = c->backbone.size();
+                const ConvParams &q1 = c->backbone[n - 3].c.p, &q2 = c->backbone[n - 2].c.p, &q3 = c->backbone[n - 1].c.p;
+                const int st16 = storage_type(c);
+                if (st16 && stride == 1 && a.C == 64 && out.C == 256 && (cur.C == 64 || cur.C == 256) && q1.w16 && q2.w16 && q3.w16 &&
+                    q1.x_st == st16 && q1.y_st == st16 && q2.y_st == st16 && q3.y_st == st16 && q3.res_st == st16 && q2.KWCp == 192 &&
+                    q1.KWCp == cur.C && q3.KWCp == 64 && (size_t)B * cur.H * cur.W * cur.C * 2 < 0xfffffff0ull &&
+                    !getenv("APSE_NO_BNECK_FUSE")) {
+                    Step fs;
+                    fs.kind = S_BNECK;
+                    fs.c = c->backbone[n - 3].c;
+                    fs.c.name = P + ".fused";
+                    fs.c.flops_per_item = c->backbone[n - 3].c.flops_per_item + c->backbone[n - 2].c.flops_per_item + c->backbone[n - 1].c.flops_per_item;
+                    fs.p2 = q2; fs.p3 = q3;
+                    fs.x = cur.p; fs.y = out.p; fs.H = cur.H; fs.W = cur.W; fs.C = cur.C; fs.st = st16;
+                    c->backbone.resize(n - 3);
+                    c->backbone.push_back(fs);
+                }
+            }
             cur = out;
         }
     }
@@ -1146,7 +1183,7 @@ int apse_debug_tensor(apse_ctx* c, const char* name, void* dst, size_t max_bytes
 double apse_flops(apse_ctx* c, int batch, double proposals, double detections) {
     if (!c || !c->finalized) return 0.0;
     double f = 0;
-    for (auto& s : c->backbone) if (s.kind == S_CONV) f += s.c.flops_per_item * batch;
+    for (auto& s : c->backbone) if (s.kind == S_CONV || s.kind == S_BNECK) f += s.c.flops_per_item * batch;
     for (auto& s : c->rpnhead) f += s.c.flops_per_item * batch;
     for (auto& s : c->boxhead) f += s.c.flops_per_item * proposals;
     for (auto& s : c->maskhead) f += s.c.flops_per_item * detections;

@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 CFG_NAMES = ["conv_igemm<128x128>", "conv_igemm<64x64>", "conv_igemm<128x32>", "conv_igemm<128x64>",
              "conv_igemm<64x64,k32>", "conv_igemm<128x32,k32>", "conv_igemm<64x64,8 waves,k64>", "conv_igemm<64x64,8 waves,k128>",
-             "conv_igemm<256x128>", "conv1x1_stream", "(unused)", "conv_glds16<256x128>", "stem_s2d_pool16", "conv_skinny16"]
+             "conv_igemm<256x128>", "conv1x1_stream", "bottleneck64_fused16", "conv_glds16<256x128>", "stem_s2d_pool16", "conv_skinny16"]
 # template arguments <WM, WN, TM, TN, KS, XT, WK, PR> of conv_igemm_f32 behind each tile shape (f32 path, f32 activations):
 # the kernel names rocprofv3 reports, used to look the dominant kernel up in the committed PMC summary
 CFG_TEMPLATE = ["<2, 2, 2, 2, 1, 0, 1, 0>", "<2, 2, 1, 1, 2, 0, 1, 0>", "<4, 1, 1, 1, 2, 0, 1, 0>", "<4, 1, 1, 2, 1, 0, 1, 0>",

@@ -179,11 +179,12 @@ def oracle_rpn_side(post):
                 cats=pr["level"])
 
 
-def explain_detection_sets(A, B, score_thr=0.5, nms_thr=0.5, match_iou=0.9):
-    """Box-branch form of ``explain_sets`` (sides from hip_box_side / oracle_box_side)."""
+def explain_detection_sets(A, B, score_thr=0.5, nms_thr=0.5, match_iou=0.9, rank_limit=None):
+    """Box-branch form of ``explain_sets`` (sides from hip_box_side / oracle_box_side); ``rank_limit`` = DETECTIONS_PER_IMAGE
+    (the top-100 cut of fast_rcnn_inference_single_image: with a full list an item can fall past it inside the score noise)."""
     # noise sample: every candidate pair with p > 0.02 (scores are compared as logits, where the noise does not depend on p: the
     # floor only drops the thousands of background-certain candidates, whose probabilities sit at the clamp)
-    return explain_sets(_flat_box_side(A), _flat_box_side(B), score_thr, nms_thr, match_iou=match_iou, noise_floor=0.02)
+    return explain_sets(_flat_box_side(A), _flat_box_side(B), score_thr, nms_thr, rank_limit=rank_limit, match_iou=match_iou, noise_floor=0.02)
 
 
 def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise_floor=None, pre_topk=None):
@@ -431,7 +432,8 @@ def explain_frame(hip_model, post, dump=None, b=0):
     is "no counterpart candidate" is traced to its PROPOSAL: if the other run lacks that proposal and the RPN-stage
     analysis explains the proposal's absence (NMS at 0.7 / rank cut inside the measured noise), the item is explained too."""
     hb, ob = hip_box_side(hip_model, b), oracle_box_side(post)
-    rep_box, un_box = explain_detection_sets(hb, ob)
+    rep_box, un_box = explain_detection_sets(hb, ob, score_thr=float(hip_model._cfg_c.score_thresh), nms_thr=float(hip_model._cfg_c.box_nms),
+                                             rank_limit=int(hip_model._cfg_c.dets_per_image))
     hr, orr = hip_rpn_side(hip_model, b), oracle_rpn_side(post)
     post_topk = int(hip_model._cfg_c.rpn_post_topk)
     rep_rpn, un_rpn = explain_sets(hr, orr, None, float(hip_model._cfg_c.rpn_nms), rank_limit=post_topk,
@@ -473,6 +475,21 @@ def explain_frame(hip_model, post, dump=None, b=0):
                     item["explained"] = True
                     continue
         still.append(item)
+    # NMS cascades once more: an item suppressed in the other run by something only that run keeps stands or falls with that
+    # suppressor, whose presence may only just have been explained above (through its proposal)
+    by_key = {(o["side"], o["index"]): o for o in rep_box["only"]}
+    changed = True
+    while changed:
+        changed = False
+        for o in list(still):
+            if "suppressor_only_in_other" not in o:
+                continue
+            q = by_key.get(("B" if o["side"] == "A" else "A", o["suppressor_only_in_other"]))
+            if q is not None and q.get("explained"):
+                o["explained"] = True
+                o["why"] = "nms cascade: suppressed in the other run by an item only that run keeps (whose presence is explained through its proposal)"
+                still.remove(o)
+                changed = True
     if dump:
         import json
         with open(dump, "w") as f:

@@ -384,6 +384,40 @@ def test_fused_stem_pool_equals_two_kernel_form(setup, dtype, size, monkeypatch)
     assert got[0][2] == got[1][2]
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("size", [(256, 448), (270, 480), (200, 333)], ids=["tiles_whole", "tiles_ragged", "odd"])
+def test_fused_bottleneck_equals_three_kernel_form(setup, dtype, size, monkeypatch, logdir):
+    """16-bit storage modes run every res2 bottleneck (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + residual) as ONE kernel with the two
+    64-channel intermediates in LDS (csrc/bottleneck16.hip).  Everything behind it -- the output of each res2 block, p2, and every
+    live byte of the frame's results -- must be the three-kernel form's bits (APSE_NO_BNECK_FUSE, read when a context is built).
+    256x448 -> a 64x112 map (8x16 tiles fit exactly); 270x480 -> 68x120 and 200x333 -> 50x84: ragged last tile rows / columns,
+    halo pixels outside the map on every border.  Block 0 takes its residual from the projection shortcut and has 64 input
+    channels, blocks 1 / 2 are the 256-channel identity form."""
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    from hip_helpers import _live_bytes
+    frame = setup["seq"].frame(2)
+    got = []
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("APSE_NO_BNECK_FUSE", "1")
+        else:
+            monkeypatch.delenv("APSE_NO_BNECK_FUSE", raising=False)
+        cfg = _cfg()
+        cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = size
+        cfg.APSE.DTYPE = dtype
+        tr = RcnnTracker(cfg, FRAME, setup["asd"], detector_state=setup["sd"])
+        tr.predictor(frame)
+        model = tr.predictor.model
+        got.append((model.debug_tensor("res2").cpu(), model.debug_tensor("p2").cpu(), _live_bytes(model, model.last_results)))
+    assert got[0][0].shape == got[1][0].shape and got[0][0].numel() > 0
+    assert int(got[0][0].view(torch.int16).ne(0).sum()) > 0
+    same = torch.equal(got[0][0].view(torch.int16), got[1][0].view(torch.int16))
+    _log(logdir, "bneck_fused/%s/%dx%d" % (dtype, size[0], size[1]), dict(res2_equal=same, shape=list(got[0][0].shape)))
+    assert same
+    assert torch.equal(got[0][1].view(torch.int16), got[1][1].view(torch.int16))
+    assert got[0][2] == got[1][2]
+
+
 def test_assoc_fc_sliced_equals_conv_form(setup, logdir, monkeypatch):
     """The association FC as K slices + ordered reduction + normalise (roi.hip, apse_k_assoc_fc) against the split-K convolution +
     reduce + l2_normalize kernels (APSE_NO_ASSOC_FC, read when a context is built): same f32 products, another summation order."""
