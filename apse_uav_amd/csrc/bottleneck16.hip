@@ -21,10 +21,11 @@
 // 32 w .. + 31; A fragments are 16-byte reads of the t1 tile at (pixel + tap).  Phase 3 (conv3): the wave's 32 x 64 strip of
 // t2 is its A operand, N = 256 in two chunks of 128 columns with the streaming kernel's wave-private epilogue (transpose tile,
 // residual rows requested before the accumulators go through LDS, whole 128-byte segments out).
-// Weight stream: every filter slice a phase needs (conv1: Cin / 64 slices of 64 x 128 B; conv2: 9 taps of 64 x 128 B; conv3:
-// 4 chunks of 64 x 128 B) passes through a double-buffered, XOR-swizzled LDS stage shared by the four waves, fetched two
-// stages ahead through registers -- the sequence is the same for every tile, so the stream runs across tile seams and the
-// next tile's first filters are in LDS before its activations arrive.
+// Weight stream: five stages per tile -- conv1's whole filter (Cin / 64 slices of 64 x 128 B), conv2's taps three at a time
+// (3 x 64 x 128 B), conv3's whole filter (256 x 128 B) -- through ONE 32 KB XOR-swizzled LDS stage shared by the four waves; a
+// stage is fetched global -> registers while the previous one computes and handed to LDS between two barriers.  (First form of
+// this kernel: 15 stages of 8 KB, double-buffered, one barrier each -- with 0.1-0.3 us of MFMA work per stage every stage waited
+// out an L2 round trip: 28 us per tile.)  The sequence is the same for every tile, so the stream runs across tile seams.
 #include "apse_common.h"
 #include <type_traits>
 
@@ -60,11 +61,11 @@ __device__ __forceinline__ int bn_slot(int row, int ls) { return row * 128 + ((l
 template <int PR, int K1>
 __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams p) {
     typedef typename std::conditional<PR == 1, bf16x8, bn_f16x8>::type op8;
-    constexpr int NS1 = K1 / 64;                  // conv1 filter stages
-    constexpr int GT = NS1 + 9 + 4;               // stages per tile
+    constexpr int NS1 = K1 / 64;                  // conv1 filter slices
+    constexpr int GT = 5;                         // weight stages per tile: conv1 | taps 0-2 | taps 3-5 | taps 6-8 | conv3
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ws = smem;                              // [2][64 rows][128 B] weight stage (16 KB)
-    char* t1 = smem + 2 * 64 * 128;              // [192][128 B] conv1 outputs of the halo tile (24 KB)
+    char* Ws = smem;                              // [256 rows][128 B] weight stage (32 KB)
+    char* t1 = smem + 256 * 128;                  // [192][128 B] conv1 outputs of the halo tile (24 KB)
     char* t2 = t1 + 192 * 128;                    // [128][128 B] conv2 outputs of the tile (16 KB)
     float* Cw = reinterpret_cast<float*>(t1);     // phase-3 epilogue: [4 waves][32][BN_CLD] f32 (34.8 KB) over t1 + t2 (dead by then)
 
@@ -78,44 +79,50 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
     if (my_tiles == 0) return;
     const int G = my_tiles * GT;
 
-    // ---- weight stream.  Q = position of a stage inside its tile (compile time): 0 .. NS1 - 1 conv1 slices, then the 9 taps of
-    // conv2, then the 2 column chunks of conv3; the same for every tile.
-    f32x4 wr[2];
-    // filters are read through buffer descriptors: per thread two row offsets per tensor, the stage's offset is a constant
+    // ---- weight stream.  Q = position of a stage inside its tile (compile time).  Stage rows: conv1: slice * 64 + n; conv2:
+    // (tap % 3) * 64 + n; conv3: n.  Filters are read through buffer descriptors: per thread a row offset, the rest constants.
+    constexpr int NW = NS1 * 2 > 8 ? NS1 * 2 : 8;              // 16-byte pieces per thread of the largest stage
+    f32x4 wr[NW];
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w1), 0, 64 * K1 * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w2), 0, 64 * 576 * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w3), 0, 256 * 64 * 2, 0x00020000);
     auto w_fetch = [&](auto QC) {
         constexpr int Q = decltype(QC)::value;
+        if constexpr (Q == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = srow + 32 * i;
-            if constexpr (Q < NS1)
-                wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, row * (K1 * 2) + slot * 16, Q * 128, 0));
-            else if constexpr (Q < NS1 + 9)
-                wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs2, row * (576 * 2) + slot * 16,
-                                                                                         (((Q - NS1) / 3) * 192 + ((Q - NS1) % 3) * 64) * 2, 0));
-            else
-                wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs3, row * 128 + slot * 16, (Q - NS1 - 9) * 64 * 128, 0));
+            for (int i = 0; i < 2 * NS1; ++i)
+                wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs1, (srow + 32 * (i & 1)) * (K1 * 2) + slot * 16, (i >> 1) * 128, 0));
+        } else if constexpr (Q < 4) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                constexpr int T0 = 3 * (Q - 1);
+                const int t = T0 + (i >> 1);
+                wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs2, (srow + 32 * (i & 1)) * (576 * 2) + slot * 16,
+                                                                                         ((t / 3) * 192 + (t % 3) * 64) * 2, 0));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                wr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs3, (srow + 32 * i) * 128 + slot * 16, 0, 0));
         }
     };
-    auto w_store = [&](auto QC, int buf) {
+    auto w_store = [&](auto QC) {
+        constexpr int Q = decltype(QC)::value;
+        constexpr int n = Q == 0 ? 2 * NS1 : (Q < 4 ? 6 : 8);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(Ws + buf * 64 * 128 + bn_slot(srow + 32 * i, slot)) = wr[i];
+        for (int i = 0; i < n; ++i) *reinterpret_cast<f32x4*>(Ws + bn_slot(srow + 32 * i, slot)) = wr[i];
     };
     w_fetch(std::integral_constant<int, 0>{});
-    w_store(std::integral_constant<int, 0>{}, 0);
-    w_fetch(std::integral_constant<int, 1>{});                 // GT >= 12: stage 1 always exists
-    __syncthreads();
     int g = 0;
-    // one stage (position Q of its tile): hand stage g + 1 to the other buffer, request stage g + 2, run `body(Wb)` on stage g, barrier
+    // one stage (position Q of its tile; its filters are in `wr`): barrier (the previous stage's readers are done) -> registers to
+    // LDS -> request the next stage -> barrier -> `body()`
     auto stage = [&](auto QC, auto body) {
         constexpr int Q = decltype(QC)::value;
-        const int buf = g & 1;
-        if (g + 1 < G) w_store(std::integral_constant<int, (Q + 1) % GT>{}, buf ^ 1);
-        if (g + 2 < G) w_fetch(std::integral_constant<int, (Q + 2) % GT>{});
-        body(Ws + buf * 64 * 128);
         __syncthreads();
+        w_store(std::integral_constant<int, Q>{});
+        if (g + 1 < G) w_fetch(std::integral_constant<int, (Q + 1) % GT>{});
+        __syncthreads();
+        body();
         ++g;
     };
 
@@ -170,22 +177,19 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
-        auto p1 = [&](auto SC) {
-            constexpr int s = decltype(SC)::value;
-            stage(std::integral_constant<int, s>{}, [&](const char* Wb) {
+        stage(std::integral_constant<int, 0>{}, [&]() {
+#pragma unroll
+            for (int s = 0; s < NS1; ++s)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int ls = 2 * c + fh;
-                    const f32x4 bf0 = *reinterpret_cast<const f32x4*>(Wb + bn_slot(fr, ls));
-                    const f32x4 bf1 = *reinterpret_cast<const f32x4*>(Wb + bn_slot(32 + fr, ls));
+                    const f32x4 bf0 = *reinterpret_cast<const f32x4*>(Ws + bn_slot(s * 64 + fr, ls));
+                    const f32x4 bf1 = *reinterpret_cast<const f32x4*>(Ws + bn_slot(s * 64 + 32 + fr, ls));
                     acc[0] = bn_mfma(__builtin_bit_cast(op8, a0[s][c]), __builtin_bit_cast(op8, bf0), acc[0]);
                     acc[1] = bn_mfma(__builtin_bit_cast(op8, a0[s][c]), __builtin_bit_cast(op8, bf1), acc[1]);
                     acc[2] = bn_mfma(__builtin_bit_cast(op8, a1[s][c]), __builtin_bit_cast(op8, nt1 ? bf1 : bf0), acc[2]);
                 }
-            });
-        };
-        p1(std::integral_constant<int, 0>{});
-        if constexpr (NS1 > 1) { p1(std::integral_constant<int, 1>{}); p1(std::integral_constant<int, 2>{}); p1(std::integral_constant<int, 3>{}); }
+        });
         {
             // bias, ReLU, zero outside the map, one rounding -> t1
             const float bi0 = p.b1[fr], bi1 = p.b1[32 + fr];
@@ -203,31 +207,34 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
                 *reinterpret_cast<uint16_t*>(t1 + bn_slot(r1, 4 * nt1 + (fr >> 3)) + (fr & 7) * 2) = bn_round<PR>(u2);
             }
         }
-        __syncthreads();                                      // the halo tile of conv1 outputs is complete
+        // (the first barrier of the next stage is also "the halo tile of conv1 outputs is complete")
 
         // ================================================================== phase 2: conv2 3x3 from the t1 tile
         const int q2 = wave * 32 + fr;                        // output pixel of this lane's A row: (q2 / 16, q2 % 16)
         const int hbase = (q2 >> 4) * BN_HW + (q2 & 15);      // halo row of tap (0, 0)
 #pragma unroll
         for (int v = 0; v < 16; ++v) { acc[0][v] = 0.f; acc[1][v] = 0.f; }
-        auto p2 = [&](auto TC) {
-            constexpr int t = decltype(TC)::value;
-            stage(std::integral_constant<int, NS1 + t>{}, [&](const char* Wb) {
-                const int hr = hbase + (t / 3) * BN_HW + (t % 3);
+        auto p2 = [&](auto QC) {
+            constexpr int Q = decltype(QC)::value;                // stage 1 .. 3: taps 3 (Q - 1) .. + 2
+            stage(std::integral_constant<int, Q>{}, [&]() {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int ls = 2 * c + fh;
-                    const f32x4 af = *reinterpret_cast<const f32x4*>(t1 + bn_slot(hr, ls));
-                    const f32x4 bf0 = *reinterpret_cast<const f32x4*>(Wb + bn_slot(fr, ls));
-                    const f32x4 bf1 = *reinterpret_cast<const f32x4*>(Wb + bn_slot(32 + fr, ls));
-                    acc[0] = bn_mfma(__builtin_bit_cast(op8, af), __builtin_bit_cast(op8, bf0), acc[0]);
-                    acc[1] = bn_mfma(__builtin_bit_cast(op8, af), __builtin_bit_cast(op8, bf1), acc[1]);
+                for (int tl = 0; tl < 3; ++tl) {
+                    constexpr int T0 = 3 * (Q - 1);
+                    const int t = T0 + tl;
+                    const int hr = hbase + (t / 3) * BN_HW + (t % 3);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int ls = 2 * c + fh;
+                        const f32x4 af = *reinterpret_cast<const f32x4*>(t1 + bn_slot(hr, ls));
+                        const f32x4 bf0 = *reinterpret_cast<const f32x4*>(Ws + bn_slot(tl * 64 + fr, ls));
+                        const f32x4 bf1 = *reinterpret_cast<const f32x4*>(Ws + bn_slot(tl * 64 + 32 + fr, ls));
+                        acc[0] = bn_mfma(__builtin_bit_cast(op8, af), __builtin_bit_cast(op8, bf0), acc[0]);
+                        acc[1] = bn_mfma(__builtin_bit_cast(op8, af), __builtin_bit_cast(op8, bf1), acc[1]);
+                    }
                 }
             });
         };
-        p2(std::integral_constant<int, 0>{}); p2(std::integral_constant<int, 1>{}); p2(std::integral_constant<int, 2>{});
-        p2(std::integral_constant<int, 3>{}); p2(std::integral_constant<int, 4>{}); p2(std::integral_constant<int, 5>{});
-        p2(std::integral_constant<int, 6>{}); p2(std::integral_constant<int, 7>{}); p2(std::integral_constant<int, 8>{});
+        p2(std::integral_constant<int, 1>{}); p2(std::integral_constant<int, 2>{}); p2(std::integral_constant<int, 3>{});
         {
             const float bi0 = p.b2[fr], bi1 = p.b2[32 + fr];
 #pragma unroll
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
         f32x4 a3[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) a3[c] = *reinterpret_cast<const f32x4*>(t2 + bn_slot(wave * 32 + fr, 2 * c + fh));
-        __syncthreads();                                      // every wave holds its strip: t1 / t2 become the transpose tiles
+        // (the first barrier of the conv3 stage is also "every wave holds its strip": t1 / t2 then become the transpose tiles)
         auto p3 = [&](auto CC) {
             constexpr int ch = decltype(CC)::value;               // 64-column chunk of the 256 output channels
             const int nb = ch * 64 + ecol;
@@ -268,16 +275,14 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) ac3[j][v] = 0.f;
-            stage(std::integral_constant<int, NS1 + 9 + ch>{}, [&](const char* Wb) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int ls = 2 * c + fh;
-                    const f32x4 bf0 = *reinterpret_cast<const f32x4*>(Wb + bn_slot(fr, ls));
-                    const f32x4 bf1 = *reinterpret_cast<const f32x4*>(Wb + bn_slot(32 + fr, ls));
-                    ac3[0] = bn_mfma(__builtin_bit_cast(op8, a3[c]), __builtin_bit_cast(op8, bf0), ac3[0]);
-                    ac3[1] = bn_mfma(__builtin_bit_cast(op8, a3[c]), __builtin_bit_cast(op8, bf1), ac3[1]);
-                }
-            });
+            for (int c = 0; c < 4; ++c) {
+                const int ls = 2 * c + fh;
+                const f32x4 bf0 = *reinterpret_cast<const f32x4*>(Ws + bn_slot(ch * 64 + fr, ls));
+                const f32x4 bf1 = *reinterpret_cast<const f32x4*>(Ws + bn_slot(ch * 64 + 32 + fr, ls));
+                ac3[0] = bn_mfma(__builtin_bit_cast(op8, a3[c]), __builtin_bit_cast(op8, bf0), ac3[0]);
+                ac3[1] = bn_mfma(__builtin_bit_cast(op8, a3[c]), __builtin_bit_cast(op8, bf1), ac3[1]);
+            }
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -320,8 +325,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
             }
             __builtin_amdgcn_wave_barrier();
         };
-        p3(std::integral_constant<int, 0>{}); p3(std::integral_constant<int, 1>{});
-        p3(std::integral_constant<int, 2>{}); p3(std::integral_constant<int, 3>{});
+        stage(std::integral_constant<int, 4>{}, [&]() {
+            p3(std::integral_constant<int, 0>{}); p3(std::integral_constant<int, 1>{});
+            p3(std::integral_constant<int, 2>{}); p3(std::integral_constant<int, 3>{});
+        });
     }
 }
 
@@ -339,7 +346,7 @@ extern "C" int apse_k_bottleneck64_fused16(const void* x, const void* res, void*
     p.tiles_y = (H + BN_TH - 1) / BN_TH; p.tiles_x = (W + BN_TW - 1) / BN_TW;
     const long tiles = (long)B * p.tiles_y * p.tiles_x;
     const int blocks = tiles < 512 ? (int)tiles : 512;             // two per CU, persistent over the tiles
-    const size_t lds = 2 * 64 * 128 + 192 * 128 + 128 * 128;
+    const size_t lds = 256 * 128 + 192 * 128 + 128 * 128;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck64_fused16<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -40,7 +40,7 @@ int apse_k_rpn_topk_stage(const RpnLevels*, const TopkJob*, int, uint64_t*, int,
 int apse_k_rpn_decode(const RpnLevels*, int, const uint64_t*, int, const int*, float, float, float, float*, float*, int*,
                       uint32_t*, int, int, hipStream_t);
 int apse_k_nms_percat(const float*, const float*, const int*, int, int, int, const uint32_t*, float, int*, int*, int,
-                      void*, int, int, hipStream_t);
+                      void*, int, int, int, hipStream_t);
 size_t apse_nms_scratch_bytes(int slots);
 int apse_k_rank_final(const float*, const float*, int, const int*, const int*, int, int, float*, float*, int*, int*, uint32_t*,
                       int, hipStream_t);
@@ -897,7 +897,7 @@ int apse_rpn_levels(apse_ctx* c, int batch, int level_mask, void* stream) {
                            (float)log(1000.0 / 16.0), c->dec_boxes, c->dec_scores, c->dec_valid, c->maxc, level_mask, batch, s);
     if (rc) return fail(c, rc, "rpn decode launch failed");
     rc = apse_k_nms_percat(c->dec_boxes, c->dec_scores, c->dec_valid, 5 * g.rpn_pre_topk, g.rpn_pre_topk, 0, c->maxc, g.rpn_nms,
-                           c->keep_idx, c->keep_cnt, 5, c->nms_scratch, first_level, batch, s);
+                           c->keep_idx, c->keep_cnt, 5, c->nms_scratch, first_level, batch, 1, s);
     if (rc) return fail(c, rc, "rpn nms launch failed");
     int* propcnt = reinterpret_cast<int*>(c->res + c->lay.prop_count);
     rc = apse_k_rank_final(c->dec_boxes, c->dec_scores, 5 * g.rpn_pre_topk, c->keep_idx, c->keep_cnt, 5, g.rpn_post_topk, c->props,
@@ -937,7 +937,7 @@ int apse_box_head(apse_ctx* c, int batch, void* stream) {
                                c->maxc + g.max_batch, c->probs, batch, s);
     if (rc) return fail(c, rc, "box candidates launch failed");
     rc = apse_k_nms_percat(c->cand_boxes, c->cand_scores, c->cand_valid, P * K, 0, K, c->maxc + g.max_batch, g.box_nms, c->keep_idx,
-                           c->keep_cnt, K, c->nms_scratch, 0, batch, s);
+                           c->keep_cnt, K, c->nms_scratch, 0, batch, 0, s);
     if (rc) return fail(c, rc, "box nms launch failed");
     rc = apse_k_rank_final(c->cand_boxes, c->cand_scores, P * K, c->keep_idx, c->keep_cnt, K, g.dets_per_image, c->det_boxes,
                            c->det_scores, c->det_entry, c->det_cnt, nullptr, batch, s);
@@ -1333,7 +1333,7 @@ int apse_nms_rank(const float* boxes, const float* scores, const int* valid, int
     hipMemcpy(maxc, &mb, 4, hipMemcpyHostToDevice);
     void* scratch = nullptr;
     if (hipMalloc(&scratch, apse_nms_scratch_bytes(8)) != hipSuccess) return APSE_E_NOMEM;
-    int rc = apse_k_nms_percat(boxes, scores, valid, n, cat_div, cat_mod, maxc, thr, keep_idx, keep_cnt, ncat, scratch, 0, 1, s);
+    int rc = apse_k_nms_percat(boxes, scores, valid, n, cat_div, cat_mod, maxc, thr, keep_idx, keep_cnt, ncat, scratch, 0, 1, 0, s);
     if (!rc) rc = apse_k_rank_final(boxes, scores, n, keep_idx, keep_cnt, ncat, topk, out_boxes, out_scores, out_index, out_count, nullptr, 1, s);
     hipStreamSynchronize(s);
     hipFree(keep_idx); hipFree(keep_cnt); hipFree(maxc); hipFree(scratch);

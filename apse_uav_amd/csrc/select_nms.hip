@@ -191,7 +191,8 @@ struct NmsScratch {
 
 __global__ __launch_bounds__(1024) void nms_prepare(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                     const int* __restrict__ valid, int n_total, int cat_div, int cat_mod,
-                                                    const uint32_t* __restrict__ maxc, NmsScratch S, int ncat, int cat_shift) {
+                                                    const uint32_t* __restrict__ maxc, NmsScratch S, int ncat, int cat_shift,
+                                                    int presorted) {
     __shared__ uint64_t keys[NMS_MAX];
     __shared__ int wsum[17];
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -222,7 +223,10 @@ __global__ __launch_bounds__(1024) void nms_prepare(const float* __restrict__ bo
     }
     int n = wsum[16];
     n = n < NMS_MAX ? n : NMS_MAX;
-    bitonic_sort_lds<NMS_MAX, 1024>(keys, tid);
+    // presorted: the entries of a category already come in (score desc, entry asc) order -- the RPN stage, whose entry
+    // l * pre_topk + i is rank i of level l's top-k list (sorted by the same key; ties by anchor index = by i) -- so the ordered
+    // compaction above IS the sorted list and the 55 barrier steps of the bitonic network are skipped
+    if (!presorted) bitonic_sort_lds<NMS_MAX, 1024>(keys, tid);
     // batched_nms numbers the categories that are present in the call: cat_shift = index of the first one
     const float off = (float)(c - cat_shift) * (__uint_as_float(maxc[b]) + 1.0f);
     float* bx = S.box + slot * 4 * NMS_MAX;
@@ -492,7 +496,7 @@ static NmsScratch carve(void* scratch, int slots) {
 }
 int apse_k_nms_percat(const float* boxes, const float* scores, const int* valid, int n_total, int cat_div, int cat_mod,
                       const uint32_t* maxc, float thr, int* keep_idx, int* keep_cnt, int ncat, void* scratch, int cat_shift,
-                      int B, hipStream_t s) {
+                      int B, int presorted, hipStream_t s) {
     static bool done = false;
     if (!done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -501,7 +505,7 @@ int apse_k_nms_percat(const float* boxes, const float* scores, const int* valid,
     }
     NmsScratch S = carve(scratch, ncat * B);
     hipLaunchKernelGGL(nms_prepare, dim3(ncat, B), dim3(1024), 0, s, boxes, scores, valid, n_total, cat_div, cat_mod, maxc, S,
-                       ncat, cat_shift);
+                       ncat, cat_shift, presorted);
     hipLaunchKernelGGL(nms_matrix, dim3(16, 16, ncat * B), dim3(64), 0, s, S, thr);
     hipLaunchKernelGGL(nms_scan, dim3(ncat, B), dim3(1024), NMS_MAX * 16 * 8, s, S, keep_idx, keep_cnt);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
