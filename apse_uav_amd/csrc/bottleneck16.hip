@@ -209,6 +209,24 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
         }
         // (the first barrier of the next stage is also "the halo tile of conv1 outputs is complete")
 
+        // residual rows of the tile (16 pieces of 16 B per lane: rows erow + 8 i, 8 channels of each 64-column chunk): requested
+        // here so that they arrive under phase 2 -- fetched chunk by chunk inside phase 3, each exposed a full L2 round trip
+        f32x4 rr[4][4];
+        unsigned pix[4];                          // element offsets: B * H * W * 256 < 2^32 (checked by the launcher)
+        bool live[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = wave * 32 + erow + 8 * i;
+            const int oy = oy0 + (q >> 4), ox = ox0 + (q & 15);
+            live[i] = oy < p.H && ox < p.W;
+            pix[i] = (unsigned)((b * p.H + oy) * p.W + ox) * 256u + (unsigned)ecol;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                rr[ch][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (live[i]) rr[ch][i] = *reinterpret_cast<const f32x4*>(p.res + pix[i] + ch * 64);          // 8 x 16 bit
+            }
+        }
+
         // ================================================================== phase 2: conv2 3x3 from the t1 tile
         const int q2 = wave * 32 + fr;                        // output pixel of this lane's A row: (q2 / 16, q2 % 16)
         const int hbase = (q2 >> 4) * BN_HW + (q2 & 15);      // halo row of tap (0, 0)
@@ -257,19 +275,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
         auto p3 = [&](auto CC) {
             constexpr int ch = decltype(CC)::value;               // 64-column chunk of the 256 output channels
             const int nb = ch * 64 + ecol;
-            // residual rows of this chunk: requested before its MFMAs
-            f32x4 rr[4];
-            unsigned pix[4];                      // element offsets: B * H * W * 256 < 2^32 (checked by the launcher)
-            bool live[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = wave * 32 + erow + 8 * i;
-                const int oy = oy0 + (q >> 4), ox = ox0 + (q & 15);
-                live[i] = oy < p.H && ox < p.W;
-                pix[i] = (unsigned)((b * p.H + oy) * p.W + ox) * 256u + (unsigned)nb;
-                rr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (live[i]) rr[i] = *reinterpret_cast<const f32x4*>(p.res + pix[i]);          // 8 x 16 bit
-            }
             f32x16 ac3[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
                 const int r = erow + 8 * i;
                 f32x4 v0 = *reinterpret_cast<const f32x4*>(cw + r * BN_CLD + ecol) + b0;
                 f32x4 v1 = *reinterpret_cast<const f32x4*>(cw + r * BN_CLD + ecol + 4) + b1;
-                const f32x4 raw = rr[i];
+                const f32x4 raw = rr[ch][i];
                 f32x4 x0, x1;
                 if constexpr (PR == 1) {
                     const unsigned q0 = __float_as_uint(raw[0]), q1 = __float_as_uint(raw[1]), q2b = __float_as_uint(raw[2]), q3 = __float_as_uint(raw[3]);
@@ -314,12 +319,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
                         bf16x8 o;
                         o[0] = (__bf16)v0[0]; o[1] = (__bf16)v0[1]; o[2] = (__bf16)v0[2]; o[3] = (__bf16)v0[3];
                         o[4] = (__bf16)v1[0]; o[5] = (__bf16)v1[1]; o[6] = (__bf16)v1[2]; o[7] = (__bf16)v1[3];
-                        APSE_NT_STORE(o, reinterpret_cast<bf16x8*>(p.y + pix[i]));
+                        APSE_NT_STORE(o, reinterpret_cast<bf16x8*>(p.y + pix[i] + ch * 64));
                     } else {
                         bn_f16x8 o;
                         o[0] = (_Float16)v0[0]; o[1] = (_Float16)v0[1]; o[2] = (_Float16)v0[2]; o[3] = (_Float16)v0[3];
                         o[4] = (_Float16)v1[0]; o[5] = (_Float16)v1[1]; o[6] = (_Float16)v1[2]; o[7] = (_Float16)v1[3];
-                        APSE_NT_STORE(o, reinterpret_cast<bn_f16x8*>(p.y + pix[i]));
+                        APSE_NT_STORE(o, reinterpret_cast<bn_f16x8*>(p.y + pix[i] + ch * 64));
                     }
                 }
             }

@@ -156,7 +156,8 @@ class TrackPredictor:
     def prefetch(self, frames):
         """Starts the upload of the frame(s) the NEXT call will be given (an HxWx3 array or a list of them) on the
         copy stream, so the 24.9 MB H2D overlaps the GPU work already enqueued.  The next call must pass the SAME array
-        object(s); anything else is uploaded afresh."""
+        object(s), unmodified since this call (the match is by identity: the bytes were staged here); anything else is uploaded
+        afresh."""
         if frames is None:
             return
         frames = list(frames) if isinstance(frames, (list, tuple)) else [frames]

@@ -209,13 +209,13 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
     Scores are compared in the space the noise is uniform in: the RPN's objectness values are logits already; the box branch's
     are softmax probabilities, whose response to the same logit noise is p (1 - p) -- 0.25 at the 0.5 threshold, 0.09 at 0.9 --
     so they are compared as log(p / (1 - p)) (``score_thr`` given).  Items are paired with ``_same_matrix``.
-    "Within eps" means within the 99.9th PERCENTILE of the deviations measured on the other candidates (round 3; rounds 1-2
-    used 1.5 x their MAXIMUM, which for bf16 was a band of 0.35 logits -- wide enough to wave through a real 0.1-0.3 logit
-    kernel error; the 99.9th percentile of the same ~2 700 samples is ~0.15).  Every disputed item also reports where it sits
+    "Within eps" means within 1.5 x the 99.9th PERCENTILE of the deviations measured on the other candidates (round 3; rounds
+    1-2 used 1.5 x their MAXIMUM, which for bf16 at 4K was a band of 0.35 logits -- wide enough to wave through a real 0.1-0.3
+    logit kernel error; 1.5 x the 99.9th percentile of the same ~2 700 samples is ~0.22, and every case reports its z).  Every disputed item also reports where it sits
     in that noise: ``sigma_of_the_others`` (RMS deviation) and ``z`` = its own deviation / sigma.
     Everything else -- including "the other run has no such candidate" -- is returned in ``unexplained``."""
-    BAND = 1.0
-    Q = 0.999
+    BAND = 1.5          # x the 99.9th percentile: with ~3 000 samples that percentile is about the third-largest value, itself a noisy
+    Q = 0.999           # estimate of the tail (round 3 saw a 5.8-sigma IoU deviation at 1.27 x it among 1 186 same-size pairs)
 
     def qband(v):
         v = torch.as_tensor(v, dtype=torch.double).reshape(-1)
@@ -384,6 +384,16 @@ def explain_sets(A, B, score_thr, nms_thr, rank_limit=None, match_iou=0.9, noise
             u_x = float(_iou_matrix(box[None], X["boxes"][jx][None])[0, 0])
             other = _iou_matrix(box[None], sub_box)[0] < match_iou if sub_box.shape[0] else torch.zeros(0, dtype=torch.bool)
             sub = du[other][:, other][du_band[other][:, other]] if int(other.sum()) else torch.zeros(0)
+            # IoU noise grows as boxes shrink (the same coordinate noise on a shorter side): where the sample allows (>= 50 pairs),
+            # take it from boxes of comparable size only (area within a factor of two of the disputed box's)
+            if int(other.sum()):
+                ar = (sub_box[:, 2] - sub_box[:, 0]) * (sub_box[:, 3] - sub_box[:, 1])
+                a0 = float((box[2] - box[0]) * (box[3] - box[1]))
+                near = other & (ar >= 0.5 * a0) & (ar <= 2.0 * a0)
+                sub2 = du[near][:, near][du_band[near][:, near]] if int(near.sum()) else torch.zeros(0)
+                if sub2.numel() >= 50:
+                    sub = sub2
+                    item["iou_noise_sample"] = "pairs of boxes with 0.5x..2x this box's area: %d" % int(sub2.numel())
             eps_u = qband(sub)                                                          # IoU noise of the pairs not involving it: 99.9th percentile
             item.update(sigma_iou_of_the_others=round(rms(sub), 6), z_iou=round((u_y - u_x) / rms(sub), 2) if rms(sub) > 0 else None)
             item.update(iou_here=round(u_x, 6), nms_margin_here=round(u_x - nms_thr, 6), iou_diff=round(u_y - u_x, 6),
