@@ -31,7 +31,9 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 // two half-waves take alternate cells of the window with 16 B per lane and are added at the end.
 // f32 sums in a fixed order: (Y, X) row-major per half-wave.
 #define RA_CAP 16
+#ifndef RA_FLIGHT
 #define RA_FLIGHT 8        // cell loads requested together per lane (the kernel is latency- / L2-bandwidth-bound)
+#endif
 
 struct RaAxis { int base, n; float w; bool ok; };
 

@@ -95,7 +95,7 @@ def test_single_frame_stages(setup, logdir):
     dbox = float((inst.pred_boxes.tensor - post["boxes"]).abs().max())
     dscore = float((inst.scores - post["scores"]).abs().max())
     _log(logdir, "dets_delta", dict(box_max_abs_px=dbox, score_max_abs=dscore))
-    assert dbox < 5e-4, dbox                   # north_star: 1e-3 on pixel positions
+    assert dbox < 1.3e-4, dbox                 # [observed 6.1e-5 frame px = 1 ulp at x ~ 400]; north_star: 1e-3 on pixel positions
     assert dscore < 2e-6, dscore               # [observed 9.5e-7]
     # ---- masks: identical pixel sets up to threshold-edge pixels; centroids equal or off by one
     bad_px = 0

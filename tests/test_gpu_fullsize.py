@@ -552,5 +552,8 @@ def test_16bit_modes_sequence_drift_vs_f32(env, logdir, golden_dir):
     with open(os.path.join(logdir, "seq_drift.json"), "w") as f:
         json.dump(table, f, indent=1)
     _log(logdir, "seq_drift", table)
-    for tag in table:
-        assert table[tag]["paired_share_of_f32"] > 0.4, table[tag]       # first run of this test: floors set after it
+    # floors at about half the observed disagreement [round 3: fp16 98.7 % of f32's detections paired, 55 of 64 frames with the same
+    # detection set, paired centroids within 6 px; bf16 + gamma (~40 threshold-level detections per frame) 81.2 % paired, p99 15 px]
+    assert table["f16_b8"]["paired_share_of_f32"] > 0.97 and table["f16_b8"]["frames_same_detection_set"] >= 46, table["f16_b8"]
+    assert table["f16_b8"]["paired_centroid_delta_max_px"] <= 12, table["f16_b8"]
+    assert table["bf16_b4_preproc"]["paired_share_of_f32"] > 0.62 and table["bf16_b4_preproc"]["paired_centroid_delta_p99_px"] <= 30, table["bf16_b4_preproc"]

@@ -10,7 +10,7 @@ O=$R/gpurun_out
 cd $R
 : > $O/${tag}_modes.txt
 run() {
-  python3 bench.py --no-cpu-baseline --throughput-depth 0 --no-entrypoint "$@" > $O/ab_line.json 2> $O/ab_err.txt || { echo "FAILED $*" >> $O/${tag}_modes.txt; tail -5 $O/ab_err.txt >> $O/${tag}_modes.txt; return 1; }
+  python3 bench.py --no-cpu-baseline --throughput-depth 0 --no-entrypoint --no-extra-modes "$@" > $O/ab_line.json 2> $O/ab_err.txt || { echo "FAILED $*" >> $O/${tag}_modes.txt; tail -5 $O/ab_err.txt >> $O/${tag}_modes.txt; return 1; }
   python3 -c "import json,sys,os; d=json.load(open('$O/ab_line.json')); print('MODE', os.environ.get('APSE_HIP_LIB','A').split('/')[-1], ' '.join(sys.argv[1:]) or 'default', ':', d['value'], 'fps, p50', d.get('p50_ms_per_frame'))" "$@" >> $O/${tag}_modes.txt
 }
 both() {
@@ -27,7 +27,7 @@ cd /tmp && export TMPDIR=/tmp
 # kernel-stats passes (library A): GPU time per step is a steadier yardstick than frames/s
 for mode in "f16b8:--dtype f16 --batch 8" "bf16b1:--dtype bf16 --batch 1" "f32b1:"; do
   name=${mode%%:*}; args=${mode#*:}
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --throughput-depth 0 --no-entrypoint $args > /dev/null 2> $O/prof_$tag.err || exit 2
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --throughput-depth 0 --no-entrypoint --no-extra-modes $args > /dev/null 2> $O/prof_$tag.err || exit 2
   cp $(find $O/prof_$tag -name "*kernel_stats.csv" | head -1) $O/${tag}_${name}_stats.csv
   rm -rf $O/prof_$tag
   python3 -c "
