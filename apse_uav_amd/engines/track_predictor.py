@@ -12,6 +12,8 @@ through ``FrameUploader`` -- two pinned staging buffers, two device buffers and 
 starts the host copy + H2D of the NEXT frame while the current one computes; ``predictor(frame)`` then finds it
 resident.  Without a prefetch the same buffers are used on the calling stream.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -20,6 +22,7 @@ from ..weights import load_detector_file
 
 
 _COPY_POOL = None
+_COPY_THREADS = max(1, int(os.environ.get("APSE_STAGE_THREADS", "4")))       # host threads of the staging copy (tools/entry_probe.py sweeps it)
 
 
 def _host_copy(dst, src):
@@ -33,8 +36,8 @@ def _host_copy(dst, src):
         return
     if _COPY_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
-        _COPY_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="apse-stage")
-    step = (n + 3) // 4
+        _COPY_POOL = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="apse-stage")
+    step = (n + _COPY_THREADS - 1) // _COPY_THREADS
     futs = [_COPY_POOL.submit(np.copyto, dst[lo:lo + step], src[lo:lo + step]) for lo in range(0, n, step)]
     for f in futs:
         f.result()
@@ -58,7 +61,7 @@ class FrameUploader:
     arrays) into the next slot's pinned buffer and enqueues the H2D on ``stream``; the slot's device buffer is
     overwritten only after its previous consumer has run (``consumed`` event, recorded by ``release``)."""
 
-    BANDS = 4
+    BANDS = max(1, int(os.environ.get("APSE_STAGE_BANDS", "4")))
 
     def __init__(self, device, input_format="BGR", nslots=2):
         self.device = torch.device(device)

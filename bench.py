@@ -10,7 +10,11 @@ CSV line.  N > 1: one process per GPU, frames sharded by rank (weak scaling), a 
 per-frame records to rank 0 after the last step, which then runs the sequential id assignment.
 
 Prints ONE JSON line (metric, value, unit, n_gpus, steps, warmup, ms_per_step, scaling, dtype, data, config, ...), plus
-  roofline     : the dominant kernel's algorithmic FLOP/s measured with HIP events inside the timed region
+  roofline     : the dominant kernel's algorithmic FLOP/s from HIP events recorded (inside libapse_hip.so, on the launch stream)
+                 around every convolution launch of a SEPARATE pass of --probe-steps steps right after the timed region
+                 -- the timed region itself carries no instrumentation;
+  modes        : (default N = 1 invocation) short un-instrumented runs of BASELINE configs[2] (bf16, batch 4, fused undistort +
+                 gamma) and configs[4] on one GPU (fp16, batch 8), each with its MFMA and HBM whole-path roofline fractions;
   cpu_baseline : the CPU oracle (oracle/, PyTorch CPU f32) timed on this host, rank 0, N = 1 only.
 """
 import argparse
