@@ -557,3 +557,32 @@ def test_16bit_modes_sequence_drift_vs_f32(env, logdir, golden_dir):
     assert table["f16_b8"]["paired_share_of_f32"] > 0.97 and table["f16_b8"]["frames_same_detection_set"] >= 46, table["f16_b8"]
     assert table["f16_b8"]["paired_centroid_delta_max_px"] <= 12, table["f16_b8"]
     assert table["bf16_b4_preproc"]["paired_share_of_f32"] > 0.62 and table["bf16_b4_preproc"]["paired_centroid_delta_p99_px"] <= 30, table["bf16_b4_preproc"]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_4k_fused_bottleneck_equals_three_kernel_form(env, logdir, dtype, monkeypatch):
+    """csrc/bottleneck16.hip at the size it was built for: 3840x2160 frames (res2 maps of 192 x 336: 24 x 21 tiles of 8 x 16, 504 per
+    image, persistent blocks walking ~2 tiles each at batch 2), batch 2, against the three-kernel form (APSE_NO_BNECK_FUSE):
+    res2, p2 and the per-image records must be the same bits."""
+    from apse_uav_amd.engines.rcnn_tracker import RcnnTracker
+    frames = [env["seq"].frame(0), env["seq"].frame(9)]
+    got = []
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("APSE_NO_BNECK_FUSE", "1")
+        else:
+            monkeypatch.delenv("APSE_NO_BNECK_FUSE", raising=False)
+        cfg = env["cfg"].clone()
+        cfg.APSE.MAX_BATCH = 2
+        cfg.APSE.DTYPE = dtype
+        cfg.APSE.STORAGE16 = True
+        tr = RcnnTracker(cfg, FRAME, env["asd"], detector_state=env["sd"])
+        out = [o["instances"] for o in tr.predictor.predict_batch(frames, want_masks=False)[0]]
+        model = tr.predictor.model
+        got.append((model.debug_tensor("res2").cpu(), model.debug_tensor("p2").cpu(), [_record_bytes(o) for o in out], [len(o) for o in out]))
+        del tr
+    _log(logdir, "bneck_fused_4k/" + dtype, dict(n=got[0][3], res2_equal=bool(torch.equal(got[0][0].view(torch.int16), got[1][0].view(torch.int16)))))
+    assert all(n > 0 for n in got[0][3])
+    assert torch.equal(got[0][0].view(torch.int16), got[1][0].view(torch.int16))
+    assert torch.equal(got[0][1].view(torch.int16), got[1][1].view(torch.int16))
+    assert got[0][2] == got[1][2]
