@@ -27,13 +27,14 @@ __device__ __forceinline__ f32x16 s1_mfma16(f16x8 a, f16x8 b, f32x16 c) { return
 
 // PR: 0 = f32 operands (x / filters f32), 1 = bf16, 2 = f16 (x stored in that type, filters pre-rounded in w16).
 // KA: the layer's K (input channels): 64, 128 or 256 -- the whole A strip of a wave lives in registers.
-template <int PR, int KA>
+// NC: columns per chunk, 128 or 64 (64: half the accumulators -- f32 with K = 128 then fits two blocks per CU; round 3).
+template <int PR, int KA, int NC = 128>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, const int chunks_per_block) {
     constexpr int ESH = PR ? 1 : 2;                 // log2(bytes per element)
     constexpr int KSTEP = PR ? 64 : 32;             // elements per 128-byte stage row
     constexpr int EPSLOT = 16 >> ESH;               // elements per 16-byte slot
     constexpr int NST = KA / KSTEP;                 // k stages per chunk
-    constexpr int NC = 128;                         // columns per chunk
+    constexpr int NJ = NC / 32;                     // 32-column MFMA tiles per chunk
     constexpr int CLD = 68;                         // row stride (floats) of the wave-private transpose tile [32][64]
     static_assert(NST >= 1 && KA % KSTEP == 0, "K must be a whole number of stages");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -78,18 +79,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
     // ---- filter stages: global stage g = (chunk - c_begin) * NST + s
     const char* wbase = (PR ? reinterpret_cast<const char*>(p.w16) : reinterpret_cast<const char*>(p.w)) + ((size_t)(slot * EPSLOT) << ESH);
     const int G = (c_end - c_begin) * NST;
-    f32x4 wr[4];
+    f32x4 wr[NJ];
     auto w_fetch = [&](int g) {
         const int ch = c_begin + g / NST, s = g - (g / NST) * NST;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NJ; ++i) {
             const size_t n = (size_t)ch * NC + srow + 32 * i;
             wr[i] = *reinterpret_cast<const f32x4*>(wbase + ((n * (size_t)p.KWCp + (size_t)s * KSTEP) << ESH));
         }
     };
     auto w_store = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NJ; ++i) {
             const int row = srow + 32 * i;
             *reinterpret_cast<f32x4*>(Ws + buf * NC * 128 + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = wr[i];
         }
@@ -103,9 +104,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
     const int erow = lane >> 3, ecol = (lane & 7) * 8;          // epilogue: lane -> (row erow + 8 i, columns ecol .. ecol + 7)
     int g = 0;
     for (int ch = c_begin; ch < c_end; ++ch) {
-        f32x16 acc[4];
+        f32x16 acc[NJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
 #pragma unroll
@@ -118,23 +119,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
             const char* Wb = Ws + buf * NC * 128;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                f32x4 bfr[4];
+                f32x4 bfr[NJ];
                 const int ls = 2 * c + fh;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const int row = j * 32 + fr;
                     bfr[j] = *reinterpret_cast<const f32x4*>(Wb + row * 128 + ((ls ^ ((row >> 1) & 7)) << 4));
                 }
                 if constexpr (PR != 0) {
                     typedef typename std::conditional<PR == 1, bf16x8, f16x8>::type op8;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[j] = s1_mfma16(__builtin_bit_cast(op8, a[s][c]), __builtin_bit_cast(op8, bfr[j]), acc[j]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < NJ; ++j)
                             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][c][k], bfr[j][k], acc[j], 0, 0, 0);
                 }
             }
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
         // ---- chunk epilogue, wave-private: two halves of 64 columns through the transpose tile
         const int n0 = ch * NC;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < NC / 64; ++hh) {
             const int nb = n0 + hh * 64 + ecol;
             // residual rows of this half: requested before the accumulators go through LDS
             constexpr int RV = PR ? 1 : 2;              // 16-byte vectors per lane and row: 8 x 16 bit, or 2 x 4 f32
@@ -247,19 +248,28 @@ bool apse_conv1x1_stream_ok(const ConvParams& p) {
     if ((((size_t)p.B * p.H * p.W) << p.cin_log2) * (p.prec ? 2 : 4) >= 0xfffffff0ull) return false;
     // residual and output live in the operand's storage type (f32 mode: f32; 16-bit modes with 16-bit storage: that type)
     if (p.y_st != p.prec || (p.res_mode != 0 && p.res_st != p.prec)) return false;
-    if (p.prec == 0) return p.x_st == 0 && p.w != nullptr && K == 64;         // f32, K = 128 / 256 (one wave per SIMD): measured equal to the tiled kernel, not used
+    // f32: K = 64; (round 3) K = 128 and K = 256 with 64-column chunks -- half the accumulators, so the A strip (64 / 128 registers)
+    // still leaves two blocks per CU (190 / 254 VGPRs).  Isolated sweep (profiles/r03_sweep_f32_stream.txt): res3 conv3 (K = 128)
+    // 26.5 us against 33.0 tiled; lateral 2 (K = 256, 64 512 rows) 81 against 92; res4 conv3 (K = 256, 4 032 rows: one chunk per
+    // block) and the stride-2 res3 shortcut measure equal to the tiled kernel, so K = 256 is taken for large maps only.  Same bits
+    // as the tiled kernel either way.
+    if (p.prec == 0) {
+        static const bool no128 = getenv("APSE_NO_STREAM_F32K128") != nullptr, no256 = getenv("APSE_NO_STREAM_F32K256") != nullptr;
+        return p.x_st == 0 && p.w != nullptr &&
+               (K == 64 || (K == 128 && !no128) || (K == 256 && !no256 && p.stride == 1 && (size_t)p.OH * p.OW >= 32768));
+    }
     return p.x_st == p.prec && p.w16 != nullptr;
 }
 
-template <int PR, int KA>
+template <int PR, int KA, int NC = 128>
 static int launch_stream(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    const size_t lds = 2 * 128 * 128 + 4 * 32 * 68 * sizeof(float);
+    const size_t lds = 2 * NC * 128 + 4 * 32 * 68 * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream<PR, KA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream<PR, KA, NC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    const int mblocks = (p.M + 127) / 128, chunks = p.Cout / 128;
+    const int mblocks = (p.M + 127) / 128, chunks = p.Cout / NC;
     // at least one block per CU (then 256..511 blocks: measured best for res4 conv3, 37 us against 42 / 50 with 2x / 4x as
     // many): split the N chunks over blockIdx.y when the row blocks alone do not fill the chip
     static const int want = getenv("APSE_STREAM_BLOCKS") ? atoi(getenv("APSE_STREAM_BLOCKS")) : 256;
@@ -268,14 +278,14 @@ static int launch_stream(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hip
     if (ysplit > chunks) ysplit = chunks;
     const int per = (chunks + ysplit - 1) / ysplit;
     if (ev0) hipEventRecord(ev0, s);
-    hipLaunchKernelGGL((conv1x1_stream<PR, KA>), dim3(mblocks, (chunks + per - 1) / per), dim3(256), lds, s, p, per);
+    hipLaunchKernelGGL((conv1x1_stream<PR, KA, NC>), dim3(mblocks, (chunks + per - 1) / per), dim3(256), lds, s, p, per);
     if (ev1) hipEventRecord(ev1, s);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 
 int apse_launch_conv1x1_stream(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const int K = 1 << p.cin_log2;
-    if (p.prec == 0) return launch_stream<0, 64>(p, s, ev0, ev1);
+    if (p.prec == 0) return K == 64 ? launch_stream<0, 64>(p, s, ev0, ev1) : (K == 128 ? launch_stream<0, 128, 64>(p, s, ev0, ev1) : launch_stream<0, 256, 64>(p, s, ev0, ev1));
     if (p.prec == 1) {
         if (K == 64) return launch_stream<1, 64>(p, s, ev0, ev1);
         if (K == 128) return launch_stream<1, 128>(p, s, ev0, ev1);

@@ -189,6 +189,7 @@ STREAM_CASES = [
     ("s_k256_n256_up", 1, 256, 16, 24, 256, 1, False, 2),        # FPN lateral: nearest-2x upsampled top-down add
     ("s_k256_n512_s2", 1, 256, 24, 36, 512, 2, False, 0),        # stride-2 shortcut (res3.0)
     ("s_k64_n128", 3, 64, 9, 11, 128, 1, True, 0),               # a single chunk
+    ("s_k256_n256_bigmap", 1, 256, 184, 180, 256, 1, False, 2),  # FPN lateral 2 shape class: >= 32768 rows per image (f32 takes K = 256 there)
 ]
 
 @pytest.mark.parametrize("prec", [0, 1, 2], ids=["f32", "bf16", "f16"])
@@ -200,8 +201,8 @@ def test_conv1x1_stream(case, prec, logdir):
     import zlib
     name, B, Cin, H, W, Cout, stride, relu, res_mode = case
     cfg = 9
-    if prec == 0 and Cin != 64:
-        pytest.skip("f32 operands: the streaming kernel holds K = 64 only (wider K measured equal to the tiled kernel)")
+    if prec == 0 and Cin == 256 and (stride != 1 or (H // stride) * (W // stride) < 32768):
+        pytest.skip("f32 operands, K = 256: the streaming kernel is taken for maps of >= 32768 rows only (equal to the tiled kernel below)")
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
     dt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[prec]
     r16 = lambda t: t.to(dt).to(torch.float32)

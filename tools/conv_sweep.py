@@ -13,7 +13,7 @@ SHAPES = [  # name, B, H, W, Cin, Cout, K, stride, pad
     ("res5.c2", 1, 24, 42, 512, 512, 3, 1, 1), ("res5.c1", 1, 24, 42, 2048, 512, 1, 1, 0), ("res5.c3", 1, 24, 42, 512, 2048, 1, 1, 0),
     ("res3.c2", 1, 96, 168, 128, 128, 3, 1, 1), ("res3.c3", 1, 96, 168, 128, 512, 1, 1, 0), ("res3.c1", 1, 96, 168, 512, 128, 1, 1, 0),
     ("res2.c3", 1, 192, 336, 64, 256, 1, 1, 0), ("res2.c2", 1, 192, 336, 64, 64, 3, 1, 1), ("lat2", 1, 192, 336, 256, 256, 1, 1, 0),
-    ("res2.sc", 1, 192, 336, 64, 256, 1, 1, 0), ("lat3", 1, 96, 168, 512, 256, 1, 1, 0), ("res3.c1b", 1, 96, 168, 512, 128, 1, 1, 0), ("res4.sc", 1, 96, 168, 512, 1024, 1, 2, 0), ("lat4", 1, 48, 84, 1024, 256, 1, 1, 0), ("res2.c1", 1, 192, 336, 256, 64, 1, 1, 0), ("out3", 1, 96, 168, 256, 256, 3, 1, 1), ("out2", 1, 192, 336, 256, 256, 3, 1, 1), ("fc1", 1000, 7, 7, 256, 1024, 7, 1, 0), ("mask8", 8, 14, 14, 256, 256, 3, 1, 1), ("rpn_head", 1, 1, 85932, 256, 15, 1, 1, 0), ("mlogit", 8, 28, 28, 256, 4, 1, 1, 0),
+    ("res2.sc", 1, 192, 336, 64, 256, 1, 1, 0), ("res3.sc", 1, 192, 336, 256, 512, 1, 2, 0), ("lat3", 1, 96, 168, 512, 256, 1, 1, 0), ("res3.c1b", 1, 96, 168, 512, 128, 1, 1, 0), ("res4.sc", 1, 96, 168, 512, 1024, 1, 2, 0), ("lat4", 1, 48, 84, 1024, 256, 1, 1, 0), ("res2.c1", 1, 192, 336, 256, 64, 1, 1, 0), ("out3", 1, 96, 168, 256, 256, 3, 1, 1), ("out2", 1, 192, 336, 256, 256, 3, 1, 1), ("fc1", 1000, 7, 7, 256, 1024, 7, 1, 0), ("mask8", 8, 14, 14, 256, 256, 3, 1, 1), ("rpn_head", 1, 1, 85932, 256, 15, 1, 1, 0), ("mlogit", 8, 28, 28, 256, 4, 1, 1, 0),
 ]
 PREC = 1 if "--bf16" in sys.argv else 0
 ST16 = 1 if "--st16" in sys.argv else 0          # 16-bit activation storage for x / y (and the residual with --res)
