@@ -242,7 +242,8 @@ bool apse_conv1x1_stream_ok(const ConvParams& p) {
     const int K = 1 << p.cin_log2;
     if (p.KH != 1 || p.KW != 1 || p.pad != 0 || (p.stride != 1 && p.stride != 2)) return false;
     if (K != 64 && K != 128 && K != 256) return false;
-    if (p.KWCp != K || (p.Cout & 127) != 0) return false;
+    const bool nc64 = p.prec == 0 && K != 64;                     // the 64-column-chunk instantiations (f32, K = 128 / 256)
+    if (p.KWCp != K || (p.Cout & (nc64 ? 63 : 127)) != 0) return false;
     if (p.out_mode != 0 || p.y_coff != 0 || p.y_ld != p.Cout || p.splitk != 1 || p.m_count || p.tile_cnt) return false;
     if (p.res_mode != 0 && p.res_mode != 1 && p.res_mode != 2) return false;
     if ((((size_t)p.B * p.H * p.W) << p.cin_log2) * (p.prec ? 2 : 4) >= 0xfffffff0ull) return false;

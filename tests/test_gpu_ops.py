@@ -189,7 +189,9 @@ STREAM_CASES = [
     ("s_k256_n256_up", 1, 256, 16, 24, 256, 1, False, 2),        # FPN lateral: nearest-2x upsampled top-down add
     ("s_k256_n512_s2", 1, 256, 24, 36, 512, 2, False, 0),        # stride-2 shortcut (res3.0)
     ("s_k64_n128", 3, 64, 9, 11, 128, 1, True, 0),               # a single chunk
-    ("s_k256_n256_bigmap", 1, 256, 184, 180, 256, 1, False, 2),  # FPN lateral 2 shape class: >= 32768 rows per image (f32 takes K = 256 there)
+    ("s_k256_n256_bigmap", 1, 256, 184, 180, 256, 1, False, 2),
+    ("s_k256_n64_bigmap", 1, 256, 182, 181, 64, 1, True, 0),     # res2 conv1 shape class (f32 only: N = 64 needs the 64-column chunks)
+    ("s_k128_n192", 2, 128, 15, 13, 192, 1, True, 1),            # f32 only: N a multiple of 64, not of 128  # FPN lateral 2 shape class: >= 32768 rows per image (f32 takes K = 256 there)
 ]
 
 @pytest.mark.parametrize("prec", [0, 1, 2], ids=["f32", "bf16", "f16"])
@@ -201,6 +203,8 @@ def test_conv1x1_stream(case, prec, logdir):
     import zlib
     name, B, Cin, H, W, Cout, stride, relu, res_mode = case
     cfg = 9
+    if prec != 0 and Cout % 128:
+        pytest.skip("16-bit operands: 128-column chunks only")
     if prec == 0 and Cin == 256 and (stride != 1 or (H // stride) * (W // stride) < 32768):
         pytest.skip("f32 operands, K = 256: the streaming kernel is taken for maps of >= 32768 rows only (equal to the tiled kernel below)")
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
@@ -211,12 +215,16 @@ def test_conv1x1_stream(case, prec, logdir):
     b = torch.randn(Cout, generator=g)
     ref = F.conv2d(x, r16(w), b, stride=stride)
     res = None
+    mag = ref.abs()                                   # |terms| of the final sum: bounds the f32 summation-order noise where they cancel
     if res_mode == 1:
         res = r16(torch.randn(ref.shape, generator=g))
+        mag = mag + res.abs()
         ref = ref + res
     elif res_mode == 2:
         res = r16(torch.randn(B, Cout, ref.shape[2] // 2, ref.shape[3] // 2, generator=g))
-        ref = ref + F.interpolate(res, scale_factor=2, mode="nearest")
+        up = F.interpolate(res, scale_factor=2, mode="nearest")
+        mag = mag + up.abs()
+        ref = ref + up
     if relu:
         ref = F.relu(ref)
     kw = dict(prec=prec, x_st=prec, res_st=prec if res is not None else 0, y_st=prec)
@@ -231,7 +239,7 @@ def test_conv1x1_stream(case, prec, logdir):
     else:
         ulp = 2.0 ** (-7 if prec == 1 else -10)
         diff = (out - r16(ref)).abs()
-        tol = ulp * ref.abs().clamp_min(1e-3) * 1.01 + 1e-6
+        tol = ulp * ref.abs().clamp_min(1e-3) * 1.01 + 1e-6 + 2e-6 * mag       # last term: conv + residual that cancel (8.5 M outputs in the big-map case)
         frac = float((diff > 1e-6 * ref.abs().clamp_min(1.0)).float().mean())
         same = float((out == tiled).float().mean())
         _log(logdir, "conv_stream/%d/" % prec + name, dict(max=float(diff.max()), frac_differs=frac, equal_to_tiled_frac=same))
