@@ -32,8 +32,9 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 // f32 sums in a fixed order: (Y, X) row-major per half-wave.
 #define RA_CAP 16
 #ifndef RA_FLIGHT
-#define RA_FLIGHT 8        // cell loads requested together per lane (the kernel is latency- / L2-bandwidth-bound)
-#endif
+#define RA_FLIGHT 4        // cell loads requested together per lane.  Round 3 (rocprofv3, fp16 batch 8 / f32 batch 1, us per launch): 8 loads:
+#endif                     // 195.9 / 34.8 (124 / 83 VGPRs: 4-5 waves per SIMD); 4 loads: 169.0 / 33.6 (88 / 72 VGPRs); 16 loads: 360 / 42.6;
+                           // a forced 6 blocks per CU (launch bounds) spills: 603 / 38.1
 
 struct RaAxis { int base, n; float w; bool ok; };
 
@@ -96,8 +97,11 @@ __device__ __forceinline__ f32x4 ra_bin_direct(const void* fmap, int st, size_t 
 
 #define RA_MAXR 14          // largest pooler resolution (mask head)
 
+#ifndef RA_MINBLK
+#define RA_MINBLK 1        // second argument of __launch_bounds__: minimum 256-thread blocks per CU the register budget must allow
+#endif
 template <bool ST16>
-__global__ __launch_bounds__(256) void roi_align_nhwc(const FpnMaps F, const float* __restrict__ rois,
+__global__ __launch_bounds__(256, RA_MINBLK) void roi_align_nhwc(const FpnMaps F, const float* __restrict__ rois,
                                                       const int* __restrict__ roi_img, const int* __restrict__ cnt,
                                                       const int* __restrict__ total, int per_img, int n_max, int R,
                                                       void* __restrict__ out, int out_st) {

@@ -25,6 +25,9 @@ def conv(name, M, Cout, K, per_image=True):
     layers.append((name, M, Cout, K, 2.0 * M * Cout * K))
 
 
+FUSED_BNECK = any('bottleneck64_fused16' in r['Kernel_Name'] for r in fr)      # 16-bit modes: a res2 bottleneck is one launch
+
+
 H, W = 768, 1344
 conv('stem', (H // 2) * (W // 2), 64, 147)
 h, w, cin = H // 4, W // 4, 64
@@ -36,9 +39,14 @@ for si, nb in enumerate((3, 4, 23, 3)):
         oh, ow = h // st, w // st
         if bi == 0:
             conv('res%d.sc' % (si + 2), oh * ow, cout, cin)
-        conv('res%d.c1' % (si + 2), oh * ow, mid, cin)
-        conv('res%d.c2' % (si + 2), oh * ow, mid, mid * 9)
-        conv('res%d.c3' % (si + 2), oh * ow, cout, mid)
+        if FUSED_BNECK and mid == 64 and st == 1:
+            # one launch: conv1 + conv2 + conv3; the K column shows the three K's summed, FLOPs are the three layers' algorithmic FLOPs
+            m = oh * ow * BATCH
+            layers.append(('res%d.blk' % (si + 2), m, cout, cin + mid * 9 + mid, 2.0 * m * (mid * cin + mid * mid * 9 + cout * mid)))
+        else:
+            conv('res%d.c1' % (si + 2), oh * ow, mid, cin)
+            conv('res%d.c2' % (si + 2), oh * ow, mid, mid * 9)
+            conv('res%d.c3' % (si + 2), oh * ow, cout, mid)
         h, w, cin = oh, ow, cout
 dims = {2: (192, 336, 256), 3: (96, 168, 512), 4: (48, 84, 1024), 5: (24, 42, 2048)}
 for l in (5, 4, 3, 2):
@@ -62,12 +70,14 @@ items = []
 for r in fr:
     kn = r['Kernel_Name']
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    if any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'stem_s2d_pool16', 'conv_skinny16', 'assoc_fc_slices')):
+    if any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'stem_s2d_pool16', 'conv_skinny16', 'assoc_fc_slices', 'bottleneck64_fused16')):
         # the __bf16 template argument defeats rocprofv3's demangler: fall back to the raw name
         if 'stem_s2d_pool16' in kn:
             lab = 'stem+pool fused'
         elif 'assoc_fc_slices' in kn:
             lab = 'K slices + finish'
+        elif 'bottleneck64_fused16' in kn:
+            lab = 'bneck' + (kn.split('<')[1].split('>')[0] if '<' in kn else '')
         elif 'conv_skinny16' in kn:
             lab = 'skinny' + (kn.split('<')[1].split('>')[0] if '<' in kn else '')
         elif 'conv1x1_stream' in kn:
@@ -94,7 +104,7 @@ for k, (d, fl, n) in agg.items():
 others = collections.Counter()
 for r in fr:
     kn = r['Kernel_Name']
-    if not any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'conv_splitk_reduce', 'stem_s2d_pool16', 'conv_skinny16', 'assoc_fc_')):
+    if not any(t in kn.split('(')[0] for t in ('conv_igemm', 'conv1x1_stream', 'conv_glds16', 'conv_splitk_reduce', 'stem_s2d_pool16', 'conv_skinny16', 'assoc_fc_', 'bottleneck64_fused16')):
         others[kn.split('(')[0].replace('void ', '')[:40]] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 print('non-conv kernels:')
 for k, v in others.most_common(14):
