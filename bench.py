@@ -360,7 +360,7 @@ def main():
                 and not args.no_extra_modes and blocks == (3, 4, 23, 3)):
             out["modes"] = {}
             for tag, kw in (("configs[2]: bf16 batch 4, undistort + gamma fused", dict(dtype="bf16", batch=4, preproc=True)),
-                            ("configs[4] on one GPU: f16 batch 8", dict(dtype="f16", batch=8, preproc=False))):
+                            ("configs[4] on one GPU: f16 batch 8", dict(dtype="f16", batch=8, preproc=False, in_flight=3))):
                 out["modes"][tag] = extra_mode(lib, sd, asd, frames, nres, H, W, dev_index, args.mode_steps, 0 if args.no_events else 2, **kw)
         out["build"] = build
         out["association"] = "C++ Hungarian + track store of csrc/replay.hip (NativeReplay; equal to scipy linear_sum_assignment on the tests' streams)"
@@ -381,7 +381,7 @@ HBM_ACHIEVABLE_TBS = 6.29             # MI355X_MICROARCH.md: measured copy bandw
 SUSTAINED_16BIT_TFLOPS = 1810.0       # tools/micro/mfma_peak.hip on random operands (profiles/r01b_mfma_peak.txt)
 
 
-def extra_mode(lib, sd, asd, frames, nres, H, W, dev_index, steps, probe_steps, dtype, batch, preproc, warmup=3):
+def extra_mode(lib, sd, asd, frames, nres, H, W, dev_index, steps, probe_steps, dtype, batch, preproc, warmup=3, in_flight=1):
     """A short un-instrumented run of another BASELINE configuration on the same resident frames: its own context
     (`batch` frames per step, 16-bit matrix cores + 16-bit activation storage, optionally the fused undistort + gamma), the
     whole per-frame path incl. D2H of the results block and the host association, timed like the headline (synchronise,
@@ -461,6 +461,62 @@ def extra_mode(lib, sd, asd, frames, nres, H, W, dev_index, steps, probe_steps, 
                                   "avg_launch_ms": round(ms / max(nl, 1), 5), "launches_per_step": int(nl / probe_steps),
                                   "conv_ms_per_step": round(float(prof[:, 0].sum()) / probe_steps, 3),
                                   "measured": "separate pass of %d instrumented steps after the timed steps" % probe_steps}
+    if in_flight > 1:
+        # the same batches with `in_flight` of them in flight on separate streams / contexts (weights replicated): what a STREAM
+        # configuration (configs[4]) sustains when the host keeps the GPU queue full; per-frame results are those of the single-stream
+        # run (a frame's bits do not depend on what runs beside it: tests/test_gpu_fullsize.py), latency is in_flight x a step
+        from apse_uav_amd.networks.track_rcnn import TrackRCNN
+        models = [model]
+        for _ in range(in_flight - 1):
+            m2 = TrackRCNN(cfg)
+            m2.load_state_dict(sd)
+            m2.attach_association_head(tr.association_head)
+            m2.set_camera(model._camera)
+            models.append(m2)
+        streams = [torch.cuda.Stream() for _ in range(in_flight)]
+
+        def submit(i):
+            k = i % in_flight
+            lo = (i * batch) % nres
+            bt = frames[lo:lo + batch] if lo + batch <= nres else frames[[(lo + j) % nres for j in range(batch)]]
+            with torch.cuda.stream(streams[k]):
+                models[k].preprocess_frames(bt)
+                models[k].run(batch)
+
+        def collect(i):
+            k = i % in_flight
+            with torch.cuda.stream(streams[k]):
+                res = models[k].read(batch)
+            for j in range(batch):
+                replay.step(res.record(j), i * batch + j)
+        torch.cuda.synchronize()
+        for k in range(in_flight):                      # every slot builds its context before the timed part
+            submit(k)
+            collect(k)
+        torch.cuda.synchronize()
+        lat2, pend = [], []
+        t0 = time.perf_counter()
+        for i in range(steps):
+            pend.append((i, time.perf_counter()))
+            submit(i)
+            if len(pend) == in_flight:
+                j, ts = pend.pop(0)
+                collect(j)
+                lat2.append(time.perf_counter() - ts)
+        while pend:
+            j, ts = pend.pop(0)
+            collect(j)
+            lat2.append(time.perf_counter() - ts)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        fps2 = steps * batch / dt2
+        out["batches_in_flight_%d" % in_flight] = {
+            "value": round(fps2, 3), "unit": "frames/s", "steps": steps, "p50_ms_per_batch": round(1e3 * float(np.median(lat2)), 3),
+            "whole_path_tflops": round(flops_frame * fps2 / 1e12, 2),
+            "mfma_frac_of_dense_peak_2500": round(flops_frame * fps2 / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+            "hbm_frac_of_achievable_6.29": round(out["hbm_algorithmic_bytes_per_frame"] * fps2 / 1e12 / HBM_ACHIEVABLE_TBS, 4) if "hbm_algorithmic_bytes_per_frame" in out else None,
+            "what": "%d batches of %d frames in flight on separate HIP streams / contexts, fill and drain inside the timed part" % (in_flight, batch)}
+        del models, streams
     del tr, model
     torch.cuda.empty_cache()
     return out
