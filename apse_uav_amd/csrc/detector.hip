@@ -786,7 +786,7 @@ extern "C" {
 #ifndef APSE_SRC_HASH
 #define APSE_SRC_HASH "unknown"
 #endif
-const char* apse_version(void) { return "apse_hip 0.4 (gfx950, f32 / bf16 / f16 MFMA) src " APSE_SRC_HASH; }
+const char* apse_version(void) { return "apse_hip 0.5 (gfx950, f32 / bf16 / f16 MFMA) src " APSE_SRC_HASH; }
 
 int apse_create(const apse_config* cfg, apse_ctx** out) {
     if (!cfg || !out) return fail(nullptr, APSE_E_INVALID, "null argument");
