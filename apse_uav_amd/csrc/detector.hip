@@ -118,6 +118,7 @@ struct apse_ctx {
     bool box_maxc_clean = false;
     UndistortParams cam; bool cam_on = false; LabTables* cam_lut = nullptr; void* cam_map = nullptr;     // apse_set_camera: fused undistort + gamma in apse_preprocess_frames
     int hint_total = 8;      // detections seen in the previous forward: sizes the GRID of the packed-list GEMMs, nothing else
+    hipEvent_t read_ev = nullptr; void* read_pending = nullptr;      // apse_read_results_begin / _end
     // per-kernel profiling with HIP events on the caller's stream (bench.py roofline)
     bool prof_on = false; std::vector<hipEvent_t> ev_pool; int ev_used = 0;
     struct Pending { int cfg; double flops_per_item; int count_kind; int b_mult; int batch; int e0, e1; };
@@ -810,6 +811,7 @@ void apse_destroy(apse_ctx* c) {
     hipSetDevice(c->cfg.device);
     for (void* p : c->allocs) hipFree(p);
     if (c->rf_mask) hipFree(c->rf_mask);
+    if (c->read_ev) hipEventDestroy(c->read_ev);
     delete c;
 }
 
@@ -1040,11 +1042,24 @@ int apse_results_describe(apse_ctx* c, apse_results_layout* out) {
     return APSE_OK;
 }
 
-int apse_read_results(apse_ctx* c, void* host_dst, size_t bytes, void* stream) {
+// The results block goes to the host in two halves so that a caller can put work behind the copy and still get the results
+// as soon as the copy has landed: _begin enqueues the D2H and records an event right behind it, _end waits for THAT event
+// (not for the stream: kernels enqueued after _begin -- the next frame's resize -- are not waited for).
+int apse_read_results_begin(apse_ctx* c, void* host_dst, size_t bytes, void* stream) {
     if (!c || !c->finalized) return fail(c, APSE_E_STATE, "not finalized");
     if (bytes < c->lay.bytes) return fail(c, APSE_E_INVALID, "results buffer too small");
+    if (!c->read_ev) HIPCHK(c, hipEventCreateWithFlags(&c->read_ev, hipEventDisableTiming));
     HIPCHK(c, hipMemcpyAsync(host_dst, c->res, c->lay.bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(c, hipEventRecord(c->read_ev, (hipStream_t)stream));
+    c->read_pending = host_dst;
+    return APSE_OK;
+}
+
+int apse_read_results_end(apse_ctx* c, void* host_dst) {
+    if (!c || !c->finalized) return fail(c, APSE_E_STATE, "not finalized");
+    if (!c->read_pending || c->read_pending != host_dst) return fail(c, APSE_E_STATE, "apse_read_results_end without a matching _begin");
+    HIPCHK(c, hipEventSynchronize(c->read_ev));
+    c->read_pending = nullptr;
     c->hint_total = *reinterpret_cast<const int*>(reinterpret_cast<const uint8_t*>(host_dst) + c->lay.total);
     if (c->prof_on) {
         const uint8_t* h = reinterpret_cast<const uint8_t*>(host_dst);
@@ -1065,6 +1080,11 @@ int apse_read_results(apse_ctx* c, void* host_dst, size_t bytes, void* stream) {
         c->ev_used = 0;
     }
     return APSE_OK;
+}
+
+int apse_read_results(apse_ctx* c, void* host_dst, size_t bytes, void* stream) {
+    int rc = apse_read_results_begin(c, host_dst, bytes, stream);
+    return rc ? rc : apse_read_results_end(c, host_dst);
 }
 
 int apse_profile(apse_ctx* c, int enable) {

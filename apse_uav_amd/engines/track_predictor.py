@@ -190,14 +190,33 @@ class TrackPredictor:
             FrameUploader.release(self._last_slot)
 
     # ------------------------------------------------------------------ inference
+    def _prestage(self):
+        """The announced next frame(s) are on their way to the device: enqueue their resize + normalise BEHIND the current forward
+        (and behind its results copy), so that the next call starts with the network itself.  The input tensor is free by then
+        (the stem read it at the start of this forward); nothing else of this forward is touched."""
+        sl = self._prefetched
+        if sl is None or self.frame_preprocessor is not None:
+            return
+        self._prefetched = None
+        torch.cuda.current_stream(self.model.device).wait_event(sl.h2d_done)
+        self.model.preprocess_frames(sl.dev, tag=sl.key)
+        FrameUploader.release(sl)
+
     def _predict(self, frames, given=None, want_masks=True, upcoming=None, rpn_levels=31):
         model = self.model
-        dev = self._upload(frames)
-        B = model.preprocess_frames(dev)
-        self._frames_consumed()
+        tag = model._input_tag
+        if tag is not None and len(tag) == len(frames) and all(a is b for a, b in zip(tag, frames)):
+            B = len(frames)                   # pre-staged behind the previous forward: the input already holds these frames
+            model._input_tag = None
+        else:
+            dev = self._upload(frames)
+            B = model.preprocess_frames(dev)
+            self._frames_consumed()
         model.run(B, given, rpn_levels)
         self.prefetch(upcoming)               # host copy + H2D of the next frame while this one computes
-        res = model.read(B)
+        model.read_begin(B)
+        self._prestage()                      # ... and its resize, behind this frame's results copy
+        res = model.read_end(B)
         from ..networks.track_rcnn import LazyFeatures
         return [model.instances_from(res, b, want_masks) for b in range(B)], LazyFeatures(model, B)
 

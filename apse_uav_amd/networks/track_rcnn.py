@@ -102,6 +102,7 @@ class TrackRCNN:
         self._lay = None
         self._host = None
         self._camera = None                   # FramePreprocessor: undistort + gamma fused into preprocess_frames
+        self._input_tag = None                # frames (objects) the network input was pre-staged with, or None
         self.last_results = None
 
     # ---- nn.Module-like surface the reference touches
@@ -140,6 +141,7 @@ class TrackRCNN:
                    self._ctx, "apse_set_camera")
 
     def _drop_ctx(self):
+        self._input_tag = None
         if self._ctx is not None:
             _lib.load().apse_destroy(self._ctx)
             self._ctx = None
@@ -227,18 +229,23 @@ class TrackRCNN:
         lib = _lib.load()
         _lib.check(getattr(lib, fn)(self._ctx, *args), self._ctx, fn)
 
-    def preprocess_frames(self, frames):
-        """frames: uint8 CUDA tensor [B, H, W, 3] (BGR).  Fused PIL-exact resize + normalise + pad."""
+    def preprocess_frames(self, frames, tag=None):
+        """frames: uint8 CUDA tensor [B, H, W, 3] (BGR).  Fused PIL-exact resize + normalise + pad.  ``tag``: what the network
+        input now holds, for a caller that stages the NEXT frame's input behind the current forward (TrackPredictor._prestage);
+        any other write of the input clears it."""
         B, H, W, _ = frames.shape
         ih, iw = resample.resize_shortest_edge(H, W, self.cfg.INPUT.MIN_SIZE_TEST, self.cfg.INPUT.MAX_SIZE_TEST)
         self._ensure_ctx((H, W), (ih, iw))
+        self._input_tag = None
         self._call("apse_preprocess_frames", _lib.ptr(frames.contiguous()), B, _lib.stream_ptr())
+        self._input_tag = tag
         return B
 
     def preprocess_images(self, images, frame_hw):
         """images: f32 CUDA tensor [B, 3, h, w] already resized (the reference's model input)."""
         B, _, h, w = images.shape
         self._ensure_ctx(frame_hw, (h, w))
+        self._input_tag = None
         self._call("apse_preprocess_images", _lib.ptr(images.contiguous()), B, _lib.stream_ptr())
         return B
 
@@ -258,7 +265,16 @@ class TrackRCNN:
         self._call("apse_embed", batch, s)
 
     def read(self, batch):
-        self._call("apse_read_results", C.c_void_p(self._host.data_ptr()), self._lay.bytes, _lib.stream_ptr())
+        self.read_begin(batch)
+        return self.read_end(batch)
+
+    def read_begin(self, batch):
+        """Enqueues the D2H of the results block; ``read_end`` waits for THAT copy only, so kernels enqueued in between (the next
+        frame's ``preprocess_frames``) run behind the current forward without delaying its results."""
+        self._call("apse_read_results_begin", C.c_void_p(self._host.data_ptr()), self._lay.bytes, _lib.stream_ptr())
+
+    def read_end(self, batch):
+        self._call("apse_read_results_end", C.c_void_p(self._host.data_ptr()))
         raw = self._host.numpy().tobytes()
         self.last_results = FrameResults(raw, self._lay, batch)
         return self.last_results

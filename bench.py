@@ -57,6 +57,9 @@ def main():
                     help="steps of the SEPARATE instrumented pass that follows the timed region: HIP-event pairs around every "
                          "convolution launch (each pair costs ~5 us of stream time, ~1.5 ms per instrumented frame, which is why "
                          "the timed region itself carries none)")
+    ap.add_argument("--no-prestage", action="store_true",
+                    help="plain loop (resize, network, read, host work strictly one after the other) instead of the software-pipelined "
+                         "single-stream loop")
     ap.add_argument("--no-extra-modes", action="store_true",
                     help="skip the short runs of BASELINE configs[2] (bf16, batch 4, fused undistort + gamma) and configs[4] "
                          "(fp16, batch 8) that the default N = 1 invocation appends as `modes`")
@@ -257,7 +260,46 @@ def main():
 
     inflight = []          # (step index, submit time)
     trace = [] if os.environ.get("APSE_BENCH_TRACE") else None      # (submit ms, collect ms) per step -> stderr
-    for i in range(args.steps):                    # the timed region carries NO instrumentation (no HIP events, no profiling calls)
+    # Single stream, one context (the headline form): the loop is software-pipelined the way TrackPredictor runs it with an announced
+    # next frame -- frame i + 1's resize + normalise is enqueued BEHIND frame i's results copy (apse_read_results_begin / _end: the
+    # copy is waited for by event, not the stream), frame i + 1's network is enqueued as soon as frame i's results are on the host, and
+    # the host association + CSV line of frame i run while the GPU already works on frame i + 1.  Every frame's work is inside the
+    # timed region; nothing runs concurrently on the GPU; results are the same bits (tests/test_gpu_ingest.py).
+    fast = depth == 1 and not args.from_host and not args.no_prestage
+    if fast:
+        m0 = models[0]
+
+        def frames_of(i):
+            idx = [(i * B + j) % nres for j in range(B)]
+            return frames[idx[0]:idx[0] + B] if idx == list(range(idx[0], idx[0] + B)) else frames[idx]
+
+        def post(i, res):
+            for b in range(B):
+                rec = res.record(b)
+                if world == 1:
+                    replay.step(rec, i * B + b)
+                else:
+                    records.append(rec)
+            account(res)
+        first = args.warmup
+        ts = time.perf_counter()
+        m0.preprocess_frames(frames_of(first))
+        m0.run(B)
+        for i in range(args.steps):
+            j = args.warmup + i
+            m0.read_begin(B)
+            more = i + 1 < args.steps
+            if more:
+                m0.preprocess_frames(frames_of(j + 1))      # behind frame j's network and its results copy
+            res = m0.read_end(B)
+            if more:
+                ts_next = time.perf_counter()
+                m0.run(B)                                   # frame j + 1's network: enqueued before the host work on frame j
+            post(j, res)
+            lat.append(time.perf_counter() - ts)
+            if more:
+                ts = ts_next
+    for i in range(0 if fast else args.steps):     # the timed region carries NO instrumentation (no HIP events, no profiling calls)
         inflight.append((args.warmup + i, time.perf_counter()))
         t_a = time.perf_counter()
         submit(args.warmup + i)
@@ -339,6 +381,8 @@ def main():
             "p50_ms_per_frame": round(1000.0 * float(np.median(lat)) / B, 3),
             "config": {"workload": "static synthetic 3840x2160 sequence, batch=%d %s, Mask R-CNN R-%s-FPN, %d GPU(s), "
                                    "frames sharded per rank" % (B, args.dtype, "101" if blocks == (3, 4, 23, 3) else str(blocks), world),
+                       "loop": ("single stream, software-pipelined: next frame's resize behind this frame's results copy, host association "
+                                "overlapped with the next frame's network" if fast else "plain"),
                        "frame": "%dx%d" % (W, H), "preproc": "undistort + gamma fused into the resize" if args.preproc else "none", "batch_per_gpu": B, "frames_in_flight": depth, "proposals_per_frame": P_sum / max(args.steps * B, 1),
                        "detections_per_frame": N_sum / max(args.steps * B, 1),
                        "gflop_per_frame_algorithmic": round(flops_frame / 1e9, 2)},
@@ -423,11 +467,31 @@ def extra_mode(lib, sd, asd, frames, nres, H, W, dev_index, steps, probe_steps, 
         step(i, False)
     torch.cuda.synchronize()
     lat = []
+
+    def batch_of(i):
+        lo = (i * batch) % nres
+        return frames[lo:lo + batch] if lo + batch <= nres else frames[[(lo + j) % nres for j in range(batch)]]
     t0 = time.perf_counter()
+    # the same software-pipelined single-stream loop as the headline (next batch's resize behind this batch's results copy)
+    ts = time.perf_counter()
+    model.preprocess_frames(batch_of(warmup))
+    model.run(batch)
     for i in range(steps):
-        ts = time.perf_counter()
-        step(warmup + i, True)
+        model.read_begin(batch)
+        more = i + 1 < steps
+        if more:
+            model.preprocess_frames(batch_of(warmup + i + 1))
+        res = model.read_end(batch)
+        if more:
+            ts_next = time.perf_counter()
+            model.run(batch)
+        for k in range(batch):
+            replay.step(res.record(k), (warmup + i) * batch + k)
+        P += int(res.prop_count[:batch].sum())
+        N += res.total
         lat.append(time.perf_counter() - ts)
+        if more:
+            ts = ts_next
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     nfr = steps * batch

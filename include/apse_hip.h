@@ -11,7 +11,7 @@
  *
  * Conventions: every function returns 0 (APSE_OK) or a negative APSE_E_* code; apse_last_error()
  * gives the text.  Pointers named *_dev are device pointers owned by the caller; `stream` is a
- * hipStream_t passed as void*.  Calls enqueue work and return; only apse_read_results synchronises.
+ * hipStream_t passed as void*.  Calls enqueue work and return; only apse_read_results (or its _end half) waits.
  * A context is bound to one device and is not thread-safe (one per process rank).
  */
 #ifndef APSE_HIP_H
@@ -142,8 +142,14 @@ int apse_forward(apse_ctx* ctx, int batch, void* stream);
 
 /* ---- results ---- */
 int apse_results_describe(apse_ctx* ctx, apse_results_layout* out);
-/* Copies the results block to host memory (layout->bytes) and synchronises the stream. */
+/* Copies the results block to host memory (layout->bytes) and waits for the copy (the implicit device sync of the reference loop:
+ * rcnn_tracker.py:132 `.cpu()`, mask_utils.py:19,23,38 `.item()`).  = _begin + _end. */
 int apse_read_results(apse_ctx* ctx, void* host_dst, size_t bytes, void* stream);
+/* The same in two halves: _begin enqueues the copy (and an event behind it) and returns; _end waits for that copy only -- work the
+ * caller enqueued on the stream in between (the NEXT frame's apse_preprocess_frames: it touches neither the results block nor anything
+ * this forward still reads) is not waited for.  host_dst must stay valid and unread until _end returns. */
+int apse_read_results_begin(apse_ctx* ctx, void* host_dst, size_t bytes, void* stream);
+int apse_read_results_end(apse_ctx* ctx, void* host_dst);
 /* Copies detection i's mask window (rows rect.y0..y1, 64-bit words (x0>>6)..((x1+63)>>6)) to dst_dev. */
 int apse_copy_mask_window(apse_ctx* ctx, int det, int x0, int y0, int x1, int y1, uint64_t* dst_dev, void* stream);
 /* Named internal tensor -> caller buffer as NCHW f32 (p2..p6, res2..res5, stem): the feature dict
