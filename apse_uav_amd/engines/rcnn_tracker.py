@@ -67,7 +67,8 @@ class RcnnTracker:
         overlap this frame's GPU work (TrackPredictor.prefetch).  Results do not depend on it."""
         self.frame_count += 1
         if 'frame_count' in self.DISPLAY_INFO: print("\nFRAME: ", self.frame_count)
-        detections, backbone_features = self.predictor(frame, upcoming=upcoming)
+        # the record path below never reads the feature dict, so the announced frame's network may be enqueued ahead (run_ahead)
+        detections, backbone_features = self.predictor(frame, upcoming=upcoming, run_ahead=upcoming is not None)
         detections = detections['instances']
         return self._finish_frame(detections, backbone_features)
 

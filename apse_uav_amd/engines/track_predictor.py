@@ -202,27 +202,44 @@ class TrackPredictor:
         self.model.preprocess_frames(sl.dev, tag=sl.key)
         FrameUploader.release(sl)
 
-    def _predict(self, frames, given=None, want_masks=True, upcoming=None, rpn_levels=31):
+    def _predict(self, frames, given=None, want_masks=True, upcoming=None, rpn_levels=31, run_ahead=False):
+        """``run_ahead`` (callers that do not read the returned feature dict after this call returns -- RcnnTracker.next_frame):
+        when the announced next frame has been staged, its NETWORK is enqueued too, right after this frame's results (and mask
+        windows) have been copied out, so the host-side association of this frame overlaps the GPU work of the next.  The next
+        call then only reads.  Stream order keeps this frame's results copy and window copies in front of everything the next
+        forward overwrites."""
         model = self.model
-        tag = model._input_tag
-        if tag is not None and len(tag) == len(frames) and all(a is b for a, b in zip(tag, frames)):
-            B = len(frames)                   # pre-staged behind the previous forward: the input already holds these frames
-            model._input_tag = None
+        rtag = model._running_tag
+        if (rtag is not None and given is None and rtag[1] == rpn_levels and len(rtag[0]) == len(frames)
+                and all(a is b for a, b in zip(rtag[0], frames))):
+            B = len(frames)                   # this frame's forward was enqueued at the end of the previous call
+            model._running_tag = None
         else:
-            dev = self._upload(frames)
-            B = model.preprocess_frames(dev)
-            self._frames_consumed()
-        model.run(B, given, rpn_levels)
+            tag = model._input_tag
+            if tag is not None and len(tag) == len(frames) and all(a is b for a, b in zip(tag, frames)):
+                B = len(frames)               # pre-staged behind the previous forward: the input already holds these frames
+                model._input_tag = None
+            else:
+                dev = self._upload(frames)
+                B = model.preprocess_frames(dev)
+                self._frames_consumed()
+            model.run(B, given, rpn_levels)
         self.prefetch(upcoming)               # host copy + H2D of the next frame while this one computes
         model.read_begin(B)
         self._prestage()                      # ... and its resize, behind this frame's results copy
         res = model.read_end(B)
         from ..networks.track_rcnn import LazyFeatures
-        return [model.instances_from(res, b, want_masks) for b in range(B)], LazyFeatures(model, B)
+        insts = [model.instances_from(res, b, want_masks) for b in range(B)]       # mask windows are copied out here
+        if run_ahead and given is None and model._input_tag is not None:
+            nxt = model._input_tag
+            model._input_tag = None
+            model.run(len(nxt), None, rpn_levels)
+            model._running_tag = (nxt, rpn_levels)
+        return insts, LazyFeatures(model, B)
 
-    def __call__(self, original_image, upcoming=None):
+    def __call__(self, original_image, upcoming=None, run_ahead=False):
         with torch.no_grad():
-            insts, feats = self._predict([original_image], upcoming=upcoming)
+            insts, feats = self._predict([original_image], upcoming=upcoming, run_ahead=run_ahead)
             return {"instances": insts[0]}, feats
 
     def predict_batch(self, frames, given=None, want_masks=True, upcoming=None):

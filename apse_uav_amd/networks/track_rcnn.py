@@ -103,6 +103,7 @@ class TrackRCNN:
         self._host = None
         self._camera = None                   # FramePreprocessor: undistort + gamma fused into preprocess_frames
         self._input_tag = None                # frames (objects) the network input was pre-staged with, or None
+        self._running_tag = None              # (frames, rpn_levels) whose forward is already enqueued and not yet read, or None
         self.last_results = None
 
     # ---- nn.Module-like surface the reference touches
@@ -142,6 +143,7 @@ class TrackRCNN:
 
     def _drop_ctx(self):
         self._input_tag = None
+        self._running_tag = None
         if self._ctx is not None:
             _lib.load().apse_destroy(self._ctx)
             self._ctx = None
@@ -237,6 +239,7 @@ class TrackRCNN:
         ih, iw = resample.resize_shortest_edge(H, W, self.cfg.INPUT.MIN_SIZE_TEST, self.cfg.INPUT.MAX_SIZE_TEST)
         self._ensure_ctx((H, W), (ih, iw))
         self._input_tag = None
+        self._running_tag = None
         self._call("apse_preprocess_frames", _lib.ptr(frames.contiguous()), B, _lib.stream_ptr())
         self._input_tag = tag
         return B
@@ -246,10 +249,12 @@ class TrackRCNN:
         B, _, h, w = images.shape
         self._ensure_ctx(frame_hw, (h, w))
         self._input_tag = None
+        self._running_tag = None
         self._call("apse_preprocess_images", _lib.ptr(images.contiguous()), B, _lib.stream_ptr())
         return B
 
     def run(self, batch, given=None, rpn_levels=31):
+        self._running_tag = None              # any forward invalidates a speculatively enqueued one (TrackPredictor run-ahead)
         s = _lib.stream_ptr()
         self._call("apse_backbone", batch, s)
         if given is None:

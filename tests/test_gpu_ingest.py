@@ -55,11 +55,17 @@ def test_announced_next_frame_equals_plain(env, plain):
     """next_frame(f_t, upcoming=f_{t+1}): the upload of frame t+1 runs on the copy stream under frame t's kernels."""
     tr = _tracker(env)
     fr = env["frames"]
-    got = [_step(tr, fr[t], t, upcoming=fr[t + 1] if t + 1 < N else None) for t in range(N)]
+    got = []
+    for t in range(N):
+        got.append(_step(tr, fr[t], t, upcoming=fr[t + 1] if t + 1 < N else None))
+        # the announced frame was uploaded, its resize staged behind this forward and its network enqueued ahead (run_ahead):
+        # the next call only reads -- or, after the last frame, nothing is left in flight
+        rt = tr.predictor.model._running_tag
+        assert (rt is not None and rt[0][0] is fr[t + 1]) if t + 1 < N else rt is None
     assert [g[2] == p[2] for g, p in zip(got, plain)] == [True] * N
     assert [(g[0], g[1]) for g in got] == [(p[0], p[1]) for p in plain]
     # and every prefetch was actually consumed (identity match), not re-uploaded
-    assert tr.predictor._prefetched is None
+    assert tr.predictor._prefetched is None and tr.predictor.model._input_tag is None
 
 
 def test_announced_frame_differs_from_given(env, plain):
@@ -130,3 +136,30 @@ def test_start_frame_dynamic_equals_tracker_started_there(env, tmp_path):
         a, b = f.read(), g.read()
     assert a == b
     assert [r.split(",")[0] for r in a.split("\n")[2:-1]] == ["3", "4", "5", "6", "7", "8"]
+
+
+def test_run_ahead_forward_discarded_when_the_caller_changes_course(env, plain):
+    """A forward enqueued ahead for the announced frame must not leak into anything else: the caller announces frame t + 1 but then
+    (a) asks the predictor for the same frame t again, (b) uses the model-level entry with given boxes, (c) carries on with the
+    sequence -- every result must be the plain loop's bytes / its own re-run's."""
+    from apse_uav_amd.sharding import pack_record
+    tr = _tracker(env)
+    fr = env["frames"]
+    a = _step(tr, fr[0], 0, upcoming=fr[1])
+    assert a[2] == plain[0][2] and tr.predictor.model._running_tag is not None
+    # (a) the predictor is asked for frame 0 again (not the announced one): fresh upload + forward, identical record
+    inst = tr.predictor(fr[0])[0]["instances"]
+    assert pack_record(inst._record, 100, 128).tobytes() == plain[0][2]
+    assert tr.predictor.model._running_tag is None
+    # (b) announce again, then a given-boxes forward of another frame through predict_batch
+    tr2 = _tracker(env)
+    _step(tr2, fr[0], 0, upcoming=fr[1])
+    boxes = np.array([[100.0, 100.0, 300.0, 260.0]], np.float32)
+    given = (boxes, np.zeros(1, np.int32), np.array([1], np.int32))
+    g1 = tr2.predictor.predict_batch([fr[2]], given=given)[0][0]["instances"]
+    g2 = _tracker(env).predictor.predict_batch([fr[2]], given=given)[0][0]["instances"]
+    assert pack_record(g1._record, 100, 128).tobytes() == pack_record(g2._record, 100, 128).tobytes()
+    # (c) the sequence continues from frame 1 after the detour of (a): ids / records as in the plain loop
+    b = _step(tr, fr[1], 1, upcoming=fr[2])
+    c = _step(tr, fr[2], 2)
+    assert (b[2], c[2]) == (plain[1][2], plain[2][2]) and (b[0], c[0]) == (plain[1][0], plain[2][0])
