@@ -95,6 +95,24 @@ class RcnnTracker:
         if metric != 'embeddings':
             raise NotImplementedError("only the 'embeddings' metric is live in the reference (rcnn_tracker.py:69)")
         if len(detections) > 0:
+            # the device part of the association (embeddings H2D, distance-matrix kernel, its D2H) runs on a stream of its own: on
+            # the predictor's stream the `.cpu()` in there would wait for everything enqueued -- with an announced next frame that is
+            # the next frame's whole network (TrackPredictor run-ahead).  Same kernel, same arithmetic.
+            # (only the record path: features handed in by a caller live on the caller's stream)
+            import contextlib
+            with (self._assoc_ctx() if getattr(detections, "_record", None) is not None else contextlib.nullcontext()):
+                self._associate(detections, backbone_features)
+
+    def _assoc_ctx(self):
+        import contextlib
+        if self.device.type != "cuda" or getattr(self, "_host_replay", False) or not torch.cuda.is_available():
+            return contextlib.nullcontext()
+        if getattr(self, "_assoc_stream", None) is None:
+            self._assoc_stream = torch.cuda.Stream(device=self.device)
+        return torch.cuda.stream(self._assoc_stream)
+
+    def _associate(self, detections, backbone_features):
+        if True:
             rec = getattr(detections, "_record", None)
             if rec is not None:
                 # embeddings already computed by the fused GPU stage; kept on the host: the sequential
