@@ -47,7 +47,7 @@ int apse_k_rank_final(const float*, const float*, int, const int*, const int*, i
 int apse_k_box_candidates(const float*, int, int, const float*, const int*, int, float, float, float, const float*, float,
                           float*, float*, int*, uint32_t*, float*, int, hipStream_t);
 int apse_k_pack_detections(const float*, const float*, const int*, const int*, int, int, int, float*, float*, int*, int*,
-                           int*, int*, int*, hipStream_t);
+                           int*, int*, int*, unsigned long long*, hipStream_t);
 int apse_k_roi_align(const FpnMaps*, const float*, const int*, const int*, const int*, int, int, int, void*, int, hipStream_t);
 int apse_k_roi_pool(const void*, int, int, int, const float*, const int*, const int*, int, int, float, float*, int, int, hipStream_t);
 int apse_k_mask_resize(const uint8_t*, int, int, int, int, int, float*, hipStream_t);
@@ -55,9 +55,9 @@ int apse_k_round16(const float*, uint16_t*, size_t, int, hipStream_t);
 int apse_k_roi_align_masked(const void*, int, int, int, int, const float*, const float*, int, int, int, float, float*, hipStream_t);
 int apse_k_l2_normalize(const float*, float*, int, const int*, int, hipStream_t);
 int apse_k_sqdist(const float*, const float*, int, int, int, float*, hipStream_t);
-int apse_k_mask_paste(const PasteParams*, int, int*, int*, hipStream_t);
-int apse_k_closest_points(const uint64_t*, const int*, const int*, const int*, const int*, const int*, const int*, int, int,
-                          int, int, int, int*, unsigned long long*, hipStream_t);
+int apse_k_mask_paste(const PasteParams*, int, unsigned long long*, int, hipStream_t);
+int apse_k_closest_points(const uint64_t*, const int*, const int*, const unsigned long long*, const int*, const int*, const int*, int,
+                          int, int, int, int, int*, int*, unsigned long long*, hipStream_t);
 int apse_k_closest_single(const uint64_t*, int, int, int, float, float, unsigned long long*, hipStream_t);
 int apse_k_undistort_gamma(const UndistortParams*, const uint8_t*, uint8_t*, const LabTables*, int, hipStream_t);
 int apse_k_bits_to_dense(const uint64_t*, const int*, int, int, int, uint8_t*, hipStream_t);
@@ -111,7 +111,7 @@ struct apse_ctx {
     // results block (device) and layout
     apse_results_layout lay; uint8_t* res = nullptr;
     // mask tail
-    uint64_t* bits = nullptr; unsigned long long* sums = nullptr; unsigned long long* cp_keys = nullptr; int wpr = 0;
+    uint64_t* bits = nullptr; unsigned long long* sums = nullptr; int wpr = 0;
     float* emb_raw = nullptr;
     float* ws_assoc = nullptr;      // [K / 128][max detections][embed_dim]: K slices of the association FC (apse_k_assoc_fc), or nullptr
     float* rf_mask = nullptr; size_t rf_mask_floats = 0;      // apse_roi_features: masks at p2 resolution (grown on demand)
@@ -750,8 +750,7 @@ static int build_plan(apse_ctx* c) {
     if (rc) return rc;
     c->wpr = (g.frame_w + 63) / 64;
     c->bits = dalloc<uint64_t>(c, (size_t)NM * g.frame_h * c->wpr, false);
-    c->sums = dalloc<unsigned long long>(c, (size_t)NM * 3);
-    c->cp_keys = dalloc<unsigned long long>(c, (size_t)NM * KD);
+    c->sums = dalloc<unsigned long long>(c, (size_t)NM * 3);      // cleared by pack_detections in front of every mask tail
     if (!c->bits) return fail(c, APSE_E_NOMEM, "mask bit planes alloc");
     // ---- association head: roi_pool(p2) -> FC (RxR valid conv) -> L2 normalise
     const int R = g.assoc_roi;
@@ -917,7 +916,7 @@ static int pack_from_dets(apse_ctx* c, int batch, hipStream_t s) {
     return apse_k_pack_detections(c->det_boxes, c->det_scores, c->det_entry, c->det_cnt, batch, g.dets_per_image, g.num_classes,
                                   (float*)(r + c->lay.box_resized), (float*)(r + c->lay.score), (int*)(r + c->lay.cls),
                                   (int*)(r + c->lay.img), (int*)(r + c->lay.roi), (int*)(r + c->lay.total),
-                                  (int*)(r + c->lay.offset), s);
+                                  (int*)(r + c->lay.offset), c->sums, s);
 }
 
 int apse_box_head(apse_ctx* c, int batch, void* stream) {
@@ -995,11 +994,12 @@ int apse_mask_tail(apse_ctx* c, int batch, void* stream) {
     p.out_h = g.frame_h; p.out_w = g.frame_w; p.words_per_row = c->wpr; p.thresh = g.mask_thresh;
     p.boxes_out = (float*)(r + c->lay.box); p.valid = (int*)(r + c->lay.valid); p.rect = (int*)(r + c->lay.rect);
     p.bits = c->bits; p.sums = c->sums;
-    rc = apse_k_mask_paste(&p, NM, (int*)(r + c->lay.centroid), (int*)(r + c->lay.mass), s);
+    unsigned long long* keys = (unsigned long long*)(r + c->lay.closest);      // raw (distance, index) keys; decoded on the host
+    rc = apse_k_mask_paste(&p, NM, keys, g.dets_per_image, s);
     if (rc) return fail(c, rc, "mask paste launch failed");
-    rc = apse_k_closest_points(c->bits, p.rect, p.valid, (int*)(r + c->lay.centroid), (int*)(r + c->lay.img),
-                               (int*)(r + c->lay.offset), total, NM, g.dets_per_image, g.frame_h, g.frame_w, c->wpr,
-                               (int*)(r + c->lay.closest), c->cp_keys, s);
+    rc = apse_k_closest_points(c->bits, p.rect, p.valid, c->sums, (int*)(r + c->lay.img), (int*)(r + c->lay.offset), total, NM,
+                               g.dets_per_image, g.frame_h, g.frame_w, c->wpr, (int*)(r + c->lay.centroid), (int*)(r + c->lay.mass),
+                               keys, s);
     return rc ? fail(c, rc, "closest points launch failed") : APSE_OK;
 }
 
@@ -1061,6 +1061,24 @@ int apse_read_results_end(apse_ctx* c, void* host_dst) {
     HIPCHK(c, hipEventSynchronize(c->read_ev));
     c->read_pending = nullptr;
     c->hint_total = *reinterpret_cast<const int*>(reinterpret_cast<const uint8_t*>(host_dst) + c->lay.total);
+    {
+        // closest-point table: the device leaves (f32 distance bits << 32 | row-major pixel index) keys, all ones = no point;
+        // the record the caller sees holds 1-based (x, y) or (-1, -1), entries past the live detections (-1, -1)
+        uint8_t* h = reinterpret_cast<uint8_t*>(host_dst) + c->lay.closest;
+        const int kd = c->cfg.dets_per_image, W = c->cfg.frame_w;
+        int live = c->hint_total < 0 ? 0 : c->hint_total;
+        if (live > c->lay.n_max) live = c->lay.n_max;
+        for (size_t t = 0; t < (size_t)c->lay.n_max * kd; ++t) {
+            unsigned long long k;
+            memcpy(&k, h + 8 * t, 8);
+            int xy[2] = {-1, -1};
+            if (t < (size_t)live * kd && k != ~0ull) {
+                const unsigned lin = (unsigned)(k & 0xffffffffu);
+                xy[0] = (int)(lin % (unsigned)W) + 1; xy[1] = (int)(lin / (unsigned)W) + 1;
+            }
+            memcpy(h + 8 * t, xy, 8);
+        }
+    }
     if (c->prof_on) {
         const uint8_t* h = reinterpret_cast<const uint8_t*>(host_dst);
         const int total = *reinterpret_cast<const int*>(h + c->lay.total);

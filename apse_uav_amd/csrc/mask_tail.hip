@@ -27,56 +27,86 @@ struct PasteParams {
     int* valid;              // [n] nonempty after scaling
     int* rect;               // [n][4] x0, y0, x1, y1 paste window
     uint64_t* bits;          // [n][out_h][words_per_row]
-    unsigned long long* sums;   // [n][3] mass, sum(x+1), sum(y+1)   (zeroed before launch)
+    unsigned long long* sums;   // [n][3] mass, sum(x+1), sum(y+1): zero when the launch starts (pack_detections clears them)
 };
 
-__global__ void det_postprocess(const PasteParams p, int n_max) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_max || i >= *p.total) return;
+#define MT_MAXDET 1024            // packed detections per forward (apse_create enforces max_batch * dets_per_image <= this)
+#define PASTE_BLOCKS 1024
+#define PASTE_BAND 16
+#define CP_BAND 32
+
+struct DetPost { float x0, y0, x1, y1; int ok, rx0, ry0, rx1, ry1; };
+// Boxes.scale / clip / nonempty + the integer paste window of detection i (detectron2 detector_postprocess)
+__device__ __forceinline__ DetPost det_post(const PasteParams& p, int i) {
+    DetPost d;
     float x0 = p.boxes[i * 4 + 0] * p.sx, y0 = p.boxes[i * 4 + 1] * p.sy;
     float x1 = p.boxes[i * 4 + 2] * p.sx, y1 = p.boxes[i * 4 + 3] * p.sy;
     const float w = (float)p.out_w, h = (float)p.out_h;
     x0 = fminf(fmaxf(x0, 0.f), w); y0 = fminf(fmaxf(y0, 0.f), h);
     x1 = fminf(fmaxf(x1, 0.f), w); y1 = fminf(fmaxf(y1, 0.f), h);
-    p.boxes_out[i * 4 + 0] = x0; p.boxes_out[i * 4 + 1] = y0; p.boxes_out[i * 4 + 2] = x1; p.boxes_out[i * 4 + 3] = y1;
-    const int ok = ((x1 - x0) > 0.f) && ((y1 - y0) > 0.f);
-    p.valid[i] = ok;
-    p.sums[i * 3 + 0] = 0; p.sums[i * 3 + 1] = 0; p.sums[i * 3 + 2] = 0;       // paste_masks accumulates into these
-    int rx0 = (int)fmaxf(floorf(x0) - 1.f, 0.f), ry0 = (int)fmaxf(floorf(y0) - 1.f, 0.f);
-    int rx1 = (int)fminf(ceilf(x1) + 1.f, w), ry1 = (int)fminf(ceilf(y1) + 1.f, h);
-    if (!ok) { rx1 = rx0; ry1 = ry0; }
-    p.rect[i * 4 + 0] = rx0; p.rect[i * 4 + 1] = ry0; p.rect[i * 4 + 2] = rx1; p.rect[i * 4 + 3] = ry1;
+    d.x0 = x0; d.y0 = y0; d.x1 = x1; d.y1 = y1;
+    d.ok = ((x1 - x0) > 0.f) && ((y1 - y0) > 0.f);
+    d.rx0 = (int)fmaxf(floorf(x0) - 1.f, 0.f); d.ry0 = (int)fmaxf(floorf(y0) - 1.f, 0.f);
+    d.rx1 = (int)fminf(ceilf(x1) + 1.f, w); d.ry1 = (int)fminf(ceilf(y1) + 1.f, h);
+    if (!d.ok) { d.rx1 = d.rx0; d.ry1 = d.ry0; }
+    return d;
 }
 
-#define PASTE_ROWSPLIT 16
+// Exclusive prefix of cnt[0..nd) (nd <= MT_MAXDET) in place, cnt[nd] = total; 256 threads, 4 entries each.
+__device__ __forceinline__ void mt_scan(int* cnt, int nd, int* wtot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = tid * 4 + k; v[k] = i < nd ? cnt[i] : 0; s += v[k]; }
+    int incl = s;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int base = incl - s;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = tid * 4 + k; if (i < nd) cnt[i] = base; base += v[k]; }
+    if (tid == 255) cnt[nd] = base;        // the last thread's running sum covers every entry (entries past nd count 0)
+    __syncthreads();
+}
+__device__ __forceinline__ int mt_find(const int* band0, int nd, int item) {   // largest i with band0[i] <= item (bands of i non-empty)
+    int lo = 0, hi = nd;                    // invariant: band0[lo] <= item < band0[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (band0[mid] <= item) lo = mid; else hi = mid; }
+    return lo;
+}
+
 // Work item = (detection, band of PASTE_BAND window rows); a 1-D grid strides over the items of the LIVE
 // detections only, so one frame-sized window is spread over ~135 blocks instead of 16.  256 threads = 4
 // waves; a wave covers 64 pixels per step; ballot -> one 64-bit word of the bit plane.
-#define MT_MAXDET 1024            // packed detections per forward (apse_create enforces max_batch * dets_per_image <= this)
-#define PASTE_BLOCKS 1024
-#define PASTE_BAND 16
-__global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_max) {
+// Every block derives the paste windows of all detections itself (one thread per detection; block 0 also writes them to the
+// record) and scans the band counts in parallel: no separate post-processing launch, no serial prefix.  The closest-point
+// keys of the NEXT launch are reset here (they live in the record's `closest` field: 8 bytes per entry either way).
+__global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_max, unsigned long long* __restrict__ keys, int kd) {
     __shared__ float prob[32 * 32];
     __shared__ unsigned long long red[4][3];
     __shared__ int band0[MT_MAXDET + 1];       // first item of each detection (prefix over live detections)
+    __shared__ int wtot[4];
+    __shared__ int yt_i[PASTE_BAND];
+    __shared__ float yt_w0[PASTE_BAND], yt_w1[PASTE_BAND];
     const int total = *p.total < n_max ? *p.total : n_max;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int i = 0; i < total && i < MT_MAXDET; ++i) {
-            band0[i] = acc;
-            const int rows = p.valid[i] ? p.rect[i * 4 + 3] - p.rect[i * 4 + 1] : 0;
-            acc += (rows + PASTE_BAND - 1) / PASTE_BAND;
-        }
-        band0[total < MT_MAXDET ? total : MT_MAXDET] = acc;
-    }
-    __syncthreads();
     const int nd = total < MT_MAXDET ? total : MT_MAXDET;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) {
+        const DetPost d = det_post(p, i);
+        band0[i] = (d.ry1 - d.ry0 + PASTE_BAND - 1) / PASTE_BAND;
+        if (blockIdx.x == 0) {
+            p.boxes_out[i * 4 + 0] = d.x0; p.boxes_out[i * 4 + 1] = d.y0; p.boxes_out[i * 4 + 2] = d.x1; p.boxes_out[i * 4 + 3] = d.y1;
+            p.valid[i] = d.ok;
+            p.rect[i * 4 + 0] = d.rx0; p.rect[i * 4 + 1] = d.ry0; p.rect[i * 4 + 2] = d.rx1; p.rect[i * 4 + 3] = d.ry1;
+        }
+    }
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total * kd; t += gridDim.x * blockDim.x) keys[t] = ~0ull;
+    __syncthreads();
+    mt_scan(band0, nd, wtot);
     const int nitems = band0[nd];
     int cur = -1;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        int i = 0;
-        while (i + 1 < nd && band0[i + 1] <= item) ++i;
+        const int i = mt_find(band0, nd, item);
         const int band = item - band0[i];
         const int M = p.M;
         if (i != cur) {
@@ -86,41 +116,53 @@ __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_ma
             cur = i;
         }
         __syncthreads();
-        const int rx0 = p.rect[i * 4 + 0], ry0 = p.rect[i * 4 + 1], rx1 = p.rect[i * 4 + 2], ry1 = p.rect[i * 4 + 3];
-        const float bx0 = p.boxes_out[i * 4 + 0], by0 = p.boxes_out[i * 4 + 1];
-        const float bx1 = p.boxes_out[i * 4 + 2], by1 = p.boxes_out[i * 4 + 3];
-        const float bw = bx1 - bx0, bh = by1 - by0;
+        const DetPost d = det_post(p, i);
+        const int rx0 = d.rx0, ry0 = d.ry0, rx1 = d.rx1, ry1 = d.ry1;
+        const float bx0 = d.x0, by0 = d.y0;
+        const float bw = d.x1 - d.x0, bh = d.y1 - d.y0;
         const float Mf = (float)M;
         uint64_t* bits = p.bits + (size_t)i * p.out_h * p.words_per_row;
         unsigned long long mass = 0, sx = 0, sy = 0;
         const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
         const int yb = ry0 + band * PASTE_BAND;
         const int ye = (yb + PASTE_BAND) < ry1 ? (yb + PASTE_BAND) : ry1;
-        for (int y = yb + wave; y < ye; y += 4) {
+        // The y terms of the band's rows are wave-uniform: threads 0..15 put them in LDS once.  A wave then takes whole
+        // 64-pixel columns: the x terms (one IEEE division per pixel) are computed once per column and reused for every row
+        // of the band -- the arithmetic of a pixel is unchanged (same expressions, same order).
+        const int nrows = ye - yb;
+        if (threadIdx.x < PASTE_BAND) {
+            const int y = yb + threadIdx.x;
             // normalised y, grid_sample unnormalise (align_corners=False)
             const float gy = ((float)y + 0.5f - by0) / bh * 2.0f - 1.0f;
             const float iy = ((gy + 1.0f) * Mf - 1.0f) / 2.0f;
             const float fy = floorf(iy);
-            const int iy0 = (int)fy, iy1 = iy0 + 1;
-            const float wy1 = iy - fy, wy0 = 1.0f - wy1;   // torch CPU grid_sample: n = y - floor(y), s = 1 - n
-            const bool y0in = (unsigned)iy0 < (unsigned)M, y1in = (unsigned)iy1 < (unsigned)M;
-            for (int w = w0; w < w1; ++w) {
-                const int x = (w << 6) + lane;
-                bool on = false;
-                if (x >= rx0 && x < rx1) {
-                    const float gx = ((float)x + 0.5f - bx0) / bw * 2.0f - 1.0f;
-                    const float ix = ((gx + 1.0f) * Mf - 1.0f) / 2.0f;
-                    const float fx = floorf(ix);
-                    const int ix0 = (int)fx, ix1 = ix0 + 1;
-                    const float wx1 = ix - fx, wx0 = 1.0f - wx1;
-                    const bool x0in = (unsigned)ix0 < (unsigned)M, x1in = (unsigned)ix1 < (unsigned)M;
-                    float v = 0.f;
-                    if (y0in && x0in) v += prob[iy0 * M + ix0] * (wy0 * wx0);
-                    if (y0in && x1in) v += prob[iy0 * M + ix1] * (wy0 * wx1);
-                    if (y1in && x0in) v += prob[iy1 * M + ix0] * (wy1 * wx0);
-                    if (y1in && x1in) v += prob[iy1 * M + ix1] * (wy1 * wx1);
-                    on = v >= p.thresh;
-                }
+            const int iy0 = (int)fy;
+            const float wy1 = iy - fy;                     // torch CPU grid_sample: n = y - floor(y), s = 1 - n
+            yt_i[threadIdx.x] = iy0; yt_w1[threadIdx.x] = wy1; yt_w0[threadIdx.x] = 1.0f - wy1;
+        }
+        __syncthreads();
+        for (int w = w0 + wave; w < w1; w += 4) {
+            const int x = (w << 6) + lane;
+            const bool xin = x >= rx0 && x < rx1;
+            const float gx = ((float)x + 0.5f - bx0) / bw * 2.0f - 1.0f;
+            const float ix = ((gx + 1.0f) * Mf - 1.0f) / 2.0f;
+            const float fx = floorf(ix);
+            const int ix0 = (int)fx, ix1 = ix0 + 1;
+            const float wx1 = ix - fx, wx0 = 1.0f - wx1;
+            const bool x0in = xin && (unsigned)ix0 < (unsigned)M, x1in = xin && (unsigned)ix1 < (unsigned)M;
+            const int cx0 = x0in ? ix0 : 0, cx1 = x1in ? ix1 : 0;
+            for (int r = 0; r < nrows; ++r) {
+                const int y = yb + r;
+                const int iy0 = yt_i[r], iy1 = iy0 + 1;
+                const float wy0 = yt_w0[r], wy1 = yt_w1[r];
+                const bool y0in = (unsigned)iy0 < (unsigned)M, y1in = (unsigned)iy1 < (unsigned)M;
+                const int r0 = (y0in ? iy0 : 0) * M, r1 = (y1in ? iy1 : 0) * M;
+                float v = 0.f;
+                if (y0in && x0in) v += prob[r0 + cx0] * (wy0 * wx0);
+                if (y0in && x1in) v += prob[r0 + cx1] * (wy0 * wx1);
+                if (y1in && x0in) v += prob[r1 + cx0] * (wy1 * wx0);
+                if (y1in && x1in) v += prob[r1 + cx1] * (wy1 * wx1);
+                const bool on = xin && v >= p.thresh;
                 const uint64_t word = __ballot(on);
                 if (lane == 0) bits[(size_t)y * p.words_per_row + w] = word;
                 if (on) { mass += 1; sx += (unsigned long long)(x + 1); sy += (unsigned long long)(y + 1); }
@@ -139,46 +181,39 @@ __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_ma
     }
 }
 
-// centroid[i] = (floor(sum_x / mass), floor(sum_y / mass)) or (-1, -1) for an empty mask
-__global__ void mask_centroids(const unsigned long long* __restrict__ sums, const int* __restrict__ total, int n_max,
-                               int* __restrict__ cent, int* __restrict__ mass_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_max || i >= *total) return;
-    const unsigned long long m = sums[i * 3];
-    mass_out[i] = (int)m;
-    cent[i * 2 + 0] = m ? (int)(sums[i * 3 + 1] / m) : -1;
-    cent[i * 2 + 1] = m ? (int)(sums[i * 3 + 2] / m) : -1;
-}
-
 // closest[i][jl] for every detection i and every target jl of the same image.  Work item = (mask i,
 // band of CP_BAND window rows); each thread scans its words once per group of 8 targets and keeps 8
 // running minima of (f32 distance bits, row-major index); block minima are merged with atomicMin on
-// 64-bit keys (order-independent), closest_finalize turns keys into 1-based (x, y).
-#define CP_BAND 32
+// 64-bit keys (order-independent) IN the record's `closest` field; the host turns a key into 1-based (x, y) when it
+// has the record (apse_read_results_end).  Prologue (every block, one thread per detection): the band prefix and the
+// centroids -- centroid[i] = (floor(sum_x / mass), floor(sum_y / mass)) or (-1, -1) for an empty mask; block 0 writes
+// them to the record.
 __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict__ bits_all, const int* __restrict__ rect,
-                                                      const int* __restrict__ valid, const int* __restrict__ cent,
+                                                      const int* __restrict__ valid, const unsigned long long* __restrict__ sums,
                                                       const int* __restrict__ img, const int* __restrict__ offset,
                                                       const int* __restrict__ total, int n_max, int kd, int out_h, int out_w,
-                                                      int words_per_row, unsigned long long* __restrict__ keys) {
+                                                      int words_per_row, unsigned long long* __restrict__ keys,
+                                                      int* __restrict__ cent_out, int* __restrict__ mass_out) {
     __shared__ int band0[MT_MAXDET + 1];
+    __shared__ int cent[MT_MAXDET][2];
     __shared__ unsigned long long best[4][8];
+    __shared__ int wtot[4];
     const int n = *total < n_max ? *total : n_max;
     const int nd = n < MT_MAXDET ? n : MT_MAXDET;
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int i = 0; i < nd; ++i) {
-            band0[i] = acc;
-            const int rows = valid[i] ? rect[i * 4 + 3] - rect[i * 4 + 1] : 0;
-            acc += (rows + CP_BAND - 1) / CP_BAND;
-        }
-        band0[nd] = acc;
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) {
+        const int rows = valid[i] ? rect[i * 4 + 3] - rect[i * 4 + 1] : 0;
+        band0[i] = (rows + CP_BAND - 1) / CP_BAND;
+        const unsigned long long m = sums[i * 3], sx = sums[i * 3 + 1], sy = sums[i * 3 + 2];
+        const int cx = m ? (int)(sx / m) : -1, cy = m ? (int)(sy / m) : -1;
+        cent[i][0] = cx; cent[i][1] = cy;
+        if (blockIdx.x == 0) { mass_out[i] = (int)m; cent_out[i * 2] = cx; cent_out[i * 2 + 1] = cy; }
     }
     __syncthreads();
+    mt_scan(band0, nd, wtot);
     const int nitems = band0[nd];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        int i = 0;
-        while (i + 1 < nd && band0[i + 1] <= item) ++i;
+        const int i = mt_find(band0, nd, item);
         const int band = item - band0[i];
         const int j0 = offset[img[i]], j1 = offset[img[i] + 1];
         const int rx0 = rect[i * 4 + 0], ry0 = rect[i * 4 + 1], rx1 = rect[i * 4 + 2], ry1 = rect[i * 4 + 3];
@@ -193,9 +228,9 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int j = jg + k;
-                const bool ok = j < j1 && cent[j * 2] >= 0;
-                px[k] = ok ? (float)cent[j * 2] : 0.f;
-                py[k] = ok ? (float)cent[j * 2 + 1] : 0.f;
+                const bool ok = j < j1 && j < nd && cent[j < nd ? j : 0][0] >= 0;
+                px[k] = ok ? (float)cent[j][0] : 0.f;
+                py[k] = ok ? (float)cent[j][1] : 0.f;
                 b[k] = ~0ull;
             }
             for (int t = threadIdx.x; t < nw * nrows; t += blockDim.x) {
@@ -226,31 +261,12 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
             __syncthreads();
             if (threadIdx.x < 8) {
                 const int j = jg + threadIdx.x;
-                if (j < j1 && cent[j * 2] >= 0) {
+                if (j < j1 && j < nd && cent[j][0] >= 0) {
                     unsigned long long v = best[0][threadIdx.x];
                     for (int q = 1; q < 4; ++q) v = best[q][threadIdx.x] < v ? best[q][threadIdx.x] : v;
                     if (v != ~0ull) atomicMin(keys + (size_t)i * kd + (j - j0), v);
                 }
             }
-        }
-    }
-}
-
-__global__ void closest_init(unsigned long long* __restrict__ keys, const int* __restrict__ total, int n_max, int kd) {
-    const int n = *total < n_max ? *total : n_max;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n * kd; t += gridDim.x * blockDim.x) keys[t] = ~0ull;
-}
-
-__global__ void closest_finalize(const unsigned long long* __restrict__ keys, const int* __restrict__ total, int n_max, int kd,
-                                 int out_w, int* __restrict__ closest) {
-    const int n = *total < n_max ? *total : n_max;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n * kd; t += gridDim.x * blockDim.x) {
-        const unsigned long long k = keys[t];
-        if (k == ~0ull) { closest[t * 2] = -1; closest[t * 2 + 1] = -1; }
-        else {
-            const unsigned lin = (unsigned)(k & 0xffffffffu);
-            closest[t * 2] = (int)(lin % (unsigned)out_w) + 1;
-            closest[t * 2 + 1] = (int)(lin / (unsigned)out_w) + 1;
         }
     }
 }
@@ -320,23 +336,18 @@ int apse_k_closest_single(const uint64_t* bits, int out_h, int out_w, int words_
     hipLaunchKernelGGL(closest_point_single, dim3(512), dim3(256), 0, s, bits, out_h, out_w, words_per_row, px, py, best_out);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
-int apse_k_mask_paste(const PasteParams* p, int n_max, int* cent, int* mass, hipStream_t s) {
+int apse_k_mask_paste(const PasteParams* p, int n_max, unsigned long long* keys, int kd, hipStream_t s) {
     if (n_max <= 0) return APSE_OK;
-    if (p->M > 32) return APSE_E_INVALID;
-    hipLaunchKernelGGL(det_postprocess, dim3((n_max + 63) / 64), dim3(64), 0, s, *p, n_max);
-    hipLaunchKernelGGL(paste_masks, dim3(PASTE_BLOCKS), dim3(256), 0, s, *p, n_max);
-    hipLaunchKernelGGL(mask_centroids, dim3((n_max + 63) / 64), dim3(64), 0, s, p->sums, p->total, n_max, cent, mass);
+    if (p->M > 32 || n_max > MT_MAXDET) return APSE_E_INVALID;
+    hipLaunchKernelGGL(paste_masks, dim3(PASTE_BLOCKS), dim3(256), 0, s, *p, n_max, keys, kd);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
-int apse_k_closest_points(const uint64_t* bits, const int* rect, const int* valid, const int* cent, const int* img,
+int apse_k_closest_points(const uint64_t* bits, const int* rect, const int* valid, const unsigned long long* sums, const int* img,
                           const int* offset, const int* total, int n_max, int kd, int out_h, int out_w, int words_per_row,
-                          int* closest, unsigned long long* keys, hipStream_t s) {
+                          int* cent, int* mass, unsigned long long* keys, hipStream_t s) {
     if (n_max <= 0) return APSE_OK;
-    const int nb = (n_max * kd + 255) / 256;
-    hipLaunchKernelGGL(closest_init, dim3(nb < 64 ? nb : 64), dim3(256), 0, s, keys, total, n_max, kd);
-    hipLaunchKernelGGL(closest_points, dim3(1024), dim3(256), 0, s, bits, rect, valid, cent, img, offset, total, n_max, kd, out_h,
-                       out_w, words_per_row, keys);
-    hipLaunchKernelGGL(closest_finalize, dim3(nb < 64 ? nb : 64), dim3(256), 0, s, keys, total, n_max, kd, out_w, closest);
+    hipLaunchKernelGGL(closest_points, dim3(1024), dim3(256), 0, s, bits, rect, valid, sums, img, offset, total, n_max, kd, out_h,
+                       out_w, words_per_row, keys, cent, mass);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_bits_to_dense(const uint64_t* bits, const int* rect4, int out_h, int out_w, int words_per_row, uint8_t* dense,

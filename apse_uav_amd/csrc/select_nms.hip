@@ -442,8 +442,11 @@ __global__ void pack_detections(const float* __restrict__ det_boxes, const float
                                 const int* __restrict__ det_entry, const int* __restrict__ det_cnt, int B, int Kd,
                                 int ncls, float* __restrict__ pk_boxes, float* __restrict__ pk_scores,
                                 int* __restrict__ pk_cls, int* __restrict__ pk_img, int* __restrict__ pk_roi,
-                                int* __restrict__ pk_total, int* __restrict__ pk_offset) {
+                                int* __restrict__ pk_total, int* __restrict__ pk_offset,
+                                unsigned long long* __restrict__ zero_sums) {
     __shared__ int offs[65];
+    // the mask tail's per-detection integer sums (paste_masks adds into them)
+    if (zero_sums) for (int i = threadIdx.x; i < B * Kd * 3; i += blockDim.x) zero_sums[i] = 0ull;
     if (threadIdx.x == 0) {
         int t = 0;
         for (int b = 0; b < B; ++b) { offs[b] = t; pk_offset[b] = t; t += det_cnt[b]; }
@@ -534,10 +537,10 @@ int apse_k_box_candidates(const float* pred, int ld, int K, const float* props, 
 }
 int apse_k_pack_detections(const float* det_boxes, const float* det_scores, const int* det_entry, const int* det_cnt, int B,
                            int Kd, int ncls, float* pk_boxes, float* pk_scores, int* pk_cls, int* pk_img, int* pk_roi,
-                           int* pk_total, int* pk_offset, hipStream_t s) {
+                           int* pk_total, int* pk_offset, unsigned long long* zero_sums, hipStream_t s) {
     if (B > 64) return APSE_E_INVALID;
     hipLaunchKernelGGL(pack_detections, dim3(1), dim3(256), 0, s, det_boxes, det_scores, det_entry, det_cnt, B, Kd, ncls,
-                       pk_boxes, pk_scores, pk_cls, pk_img, pk_roi, pk_total, pk_offset);
+                       pk_boxes, pk_scores, pk_cls, pk_img, pk_roi, pk_total, pk_offset, zero_sums);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 }

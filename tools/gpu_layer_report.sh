@@ -16,5 +16,5 @@ for l in open("gpurun_out/prof_$tag.log"):
         break
 PY
 )
-python tools/layer_report.py $f ${nd:-8 1} > gpurun_out/layer_$tag.txt 2>&1
+python tools/layer_report.py $f ${nd:-8 1} --timeline > gpurun_out/layer_$tag.txt 2>&1
 rm -rf gpurun_out/prof_$tag

@@ -109,3 +109,12 @@ for r in fr:
 print('non-conv kernels:')
 for k, v in others.most_common(14):
     print('  %-42s %8.1f us' % (k, v))
+
+if '--timeline' in sys.argv:
+    # every launch of the step in order: start offset, duration and the idle gap before it (us)
+    print('timeline (us): start  dur  gap  kernel')
+    prev_end = t0
+    for r in fr:
+        s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        print('  %8.1f %7.1f %6.1f  %s  grid=%s' % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, r['Kernel_Name'].split('(')[0][:70], r.get('Grid_Size', '')))
+        prev_end = max(prev_end, e)
