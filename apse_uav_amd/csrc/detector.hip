@@ -111,7 +111,8 @@ struct apse_ctx {
     // results block (device) and layout
     apse_results_layout lay; uint8_t* res = nullptr;
     // mask tail
-    uint64_t* bits = nullptr; unsigned long long* sums = nullptr; int wpr = 0;
+    uint64_t* bits2[2] = {nullptr, nullptr}; int bits_cur = 0, bits_read = 0;   // mask bit planes, alternating per forward (see apse_mask_tail)
+    unsigned long long* sums = nullptr; int wpr = 0;
     float* emb_raw = nullptr;
     float* ws_assoc = nullptr;      // [K / 128][max detections][embed_dim]: K slices of the association FC (apse_k_assoc_fc), or nullptr
     float* rf_mask = nullptr; size_t rf_mask_floats = 0;      // apse_roi_features: masks at p2 resolution (grown on demand)
@@ -749,9 +750,9 @@ static int build_plan(apse_ctx* c) {
                   "mask_logits", nullptr, 0, 0, 2);
     if (rc) return rc;
     c->wpr = (g.frame_w + 63) / 64;
-    c->bits = dalloc<uint64_t>(c, (size_t)NM * g.frame_h * c->wpr, false);
+    for (int k = 0; k < 2; ++k) c->bits2[k] = dalloc<uint64_t>(c, (size_t)NM * g.frame_h * c->wpr, false);
     c->sums = dalloc<unsigned long long>(c, (size_t)NM * 3);      // cleared by pack_detections in front of every mask tail
-    if (!c->bits) return fail(c, APSE_E_NOMEM, "mask bit planes alloc");
+    if (!c->bits2[0] || !c->bits2[1]) return fail(c, APSE_E_NOMEM, "mask bit planes alloc");
     // ---- association head: roi_pool(p2) -> FC (RxR valid conv) -> L2 normalise
     const int R = g.assoc_roi;
     Tens ap = make_t(c, "assoc_pooled", NM, R, R, 256);
@@ -993,11 +994,17 @@ int apse_mask_tail(apse_ctx* c, int batch, void* stream) {
     p.sx = (float)((double)g.frame_w / (double)g.image_w); p.sy = (float)((double)g.frame_h / (double)g.image_h);
     p.out_h = g.frame_h; p.out_w = g.frame_w; p.words_per_row = c->wpr; p.thresh = g.mask_thresh;
     p.boxes_out = (float*)(r + c->lay.box); p.valid = (int*)(r + c->lay.valid); p.rect = (int*)(r + c->lay.rect);
-    p.bits = c->bits; p.sums = c->sums;
+    // Two sets of bit planes, alternating per forward: a caller may enqueue the NEXT forward right behind apse_read_results_begin
+    // (nothing in it depends on this one) and still copy this forward's mask windows out afterwards (apse_copy_mask_window reads
+    // the set that belongs to the results last read).
+    c->bits_cur ^= 1;
+    if (!c->read_pending) c->bits_read = c->bits_cur;
+    uint64_t* bits = c->bits2[c->bits_cur];
+    p.bits = bits; p.sums = c->sums;
     unsigned long long* keys = (unsigned long long*)(r + c->lay.closest);      // raw (distance, index) keys; decoded on the host
     rc = apse_k_mask_paste(&p, NM, keys, g.dets_per_image, s);
     if (rc) return fail(c, rc, "mask paste launch failed");
-    rc = apse_k_closest_points(c->bits, p.rect, p.valid, c->sums, (int*)(r + c->lay.img), (int*)(r + c->lay.offset), total, NM,
+    rc = apse_k_closest_points(bits, p.rect, p.valid, c->sums, (int*)(r + c->lay.img), (int*)(r + c->lay.offset), total, NM,
                                g.dets_per_image, g.frame_h, g.frame_w, c->wpr, (int*)(r + c->lay.centroid), (int*)(r + c->lay.mass),
                                keys, s);
     return rc ? fail(c, rc, "closest points launch failed") : APSE_OK;
@@ -1052,6 +1059,7 @@ int apse_read_results_begin(apse_ctx* c, void* host_dst, size_t bytes, void* str
     HIPCHK(c, hipMemcpyAsync(host_dst, c->res, c->lay.bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(c, hipEventRecord(c->read_ev, (hipStream_t)stream));
     c->read_pending = host_dst;
+    c->bits_read = c->bits_cur;                  // the mask windows that belong to these results
     return APSE_OK;
 }
 
@@ -1130,7 +1138,7 @@ int apse_copy_mask_window(apse_ctx* c, int det, int x0, int y0, int x1, int y1, 
     if (det < 0 || det >= g.max_batch * g.dets_per_image || x0 < 0 || y0 < 0 || x1 > g.frame_w || y1 > g.frame_h || x1 <= x0 || y1 <= y0)
         return fail(c, APSE_E_INVALID, "bad mask window");
     const int w0 = x0 >> 6, w1 = (x1 + 63) >> 6;
-    const uint64_t* src = c->bits + ((size_t)det * g.frame_h + y0) * c->wpr + w0;
+    const uint64_t* src = c->bits2[c->bits_read] + ((size_t)det * g.frame_h + y0) * c->wpr + w0;
     HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)(w1 - w0) * 8, src, (size_t)c->wpr * 8, (size_t)(w1 - w0) * 8, (size_t)(y1 - y0),
                                hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return APSE_OK;

@@ -32,8 +32,28 @@ struct PasteParams {
 
 #define MT_MAXDET 1024            // packed detections per forward (apse_create enforces max_batch * dets_per_image <= this)
 #define PASTE_BLOCKS 1024
-#define PASTE_BAND 16
-#define CP_BAND 32
+// Rows of a window per work item.  The band is picked per launch from the windows' total row count so that there are enough
+// items to fill the card: a single frame's 8 windows (~4 200 rows) in 16-row bands are 275 items = one 4-wave block on each CU,
+// which runs at the latency of its own chain (round 3, rocprofv3, f32 batch 1 / fp16 batch 8, us): paste 16 rows 47 / 125,
+// 8 rows 29 / 114, 4 rows 24 / 132 (2 rows 26, 1 row 34 at batch 1); closest points 32 rows 28 / 38, 16 rows 20 / 36, 8 rows 19 / 54.
+// Results do not depend on it.
+#define PASTE_BAND_MAX 16
+#ifndef PASTE_BAND_MIN
+#define PASTE_BAND_MIN 4
+#endif
+#ifndef PASTE_ITEMS_MIN
+#define PASTE_ITEMS_MIN 3000
+#endif
+#define CP_BAND_MAX 32
+#ifndef CP_ITEMS_MIN
+#define CP_ITEMS_MIN 512
+#endif
+// largest band in {bmax, bmax/2, .., bmin} that still gives at least `want` items (rows / band is a lower bound of the item count)
+__device__ __forceinline__ int mt_pick_band(int total_rows, int bmax, int bmin, int want) {
+    int b = bmax;
+    while (b > bmin && total_rows / b < want) b >>= 1;
+    return b;
+}
 
 struct DetPost { float x0, y0, x1, y1; int ok, rx0, ry0, rx1, ry1; };
 // Boxes.scale / clip / nonempty + the integer paste window of detection i (detectron2 detector_postprocess)
@@ -75,7 +95,7 @@ __device__ __forceinline__ int mt_find(const int* band0, int nd, int item) {   /
     return lo;
 }
 
-// Work item = (detection, band of PASTE_BAND window rows); a 1-D grid strides over the items of the LIVE
+// Work item = (detection, band of `pb` window rows); a 1-D grid strides over the items of the LIVE
 // detections only, so one frame-sized window is spread over ~135 blocks instead of 16.  256 threads = 4
 // waves; a wave covers 64 pixels per step; ballot -> one 64-bit word of the bit plane.
 // Every block derives the paste windows of all detections itself (one thread per detection; block 0 also writes them to the
@@ -86,14 +106,15 @@ __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_ma
     __shared__ unsigned long long red[4][3];
     __shared__ int band0[MT_MAXDET + 1];       // first item of each detection (prefix over live detections)
     __shared__ int wtot[4];
-    __shared__ int yt_i[PASTE_BAND];
-    __shared__ float yt_w0[PASTE_BAND], yt_w1[PASTE_BAND];
+    __shared__ int yt_i[PASTE_BAND_MAX];
+    __shared__ float yt_w0[PASTE_BAND_MAX], yt_w1[PASTE_BAND_MAX];
+    __shared__ int rowsv[MT_MAXDET];
     const int total = *p.total < n_max ? *p.total : n_max;
     const int nd = total < MT_MAXDET ? total : MT_MAXDET;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < nd; i += blockDim.x) {
         const DetPost d = det_post(p, i);
-        band0[i] = (d.ry1 - d.ry0 + PASTE_BAND - 1) / PASTE_BAND;
+        band0[i] = rowsv[i] = d.ry1 - d.ry0;
         if (blockIdx.x == 0) {
             p.boxes_out[i * 4 + 0] = d.x0; p.boxes_out[i * 4 + 1] = d.y0; p.boxes_out[i * 4 + 2] = d.x1; p.boxes_out[i * 4 + 3] = d.y1;
             p.valid[i] = d.ok;
@@ -101,6 +122,11 @@ __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_ma
         }
     }
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total * kd; t += gridDim.x * blockDim.x) keys[t] = ~0ull;
+    __syncthreads();
+    mt_scan(band0, nd, wtot);                                   // band0[nd] = rows of all windows
+    const int pb = mt_pick_band(band0[nd], PASTE_BAND_MAX, PASTE_BAND_MIN, PASTE_ITEMS_MIN);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) band0[i] = (rowsv[i] + pb - 1) / pb;
     __syncthreads();
     mt_scan(band0, nd, wtot);
     const int nitems = band0[nd];
@@ -124,13 +150,13 @@ __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_ma
         uint64_t* bits = p.bits + (size_t)i * p.out_h * p.words_per_row;
         unsigned long long mass = 0, sx = 0, sy = 0;
         const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
-        const int yb = ry0 + band * PASTE_BAND;
-        const int ye = (yb + PASTE_BAND) < ry1 ? (yb + PASTE_BAND) : ry1;
+        const int yb = ry0 + band * pb;
+        const int ye = (yb + pb) < ry1 ? (yb + pb) : ry1;
         // The y terms of the band's rows are wave-uniform: threads 0..15 put them in LDS once.  A wave then takes whole
         // 64-pixel columns: the x terms (one IEEE division per pixel) are computed once per column and reused for every row
         // of the band -- the arithmetic of a pixel is unchanged (same expressions, same order).
         const int nrows = ye - yb;
-        if (threadIdx.x < PASTE_BAND) {
+        if (threadIdx.x < PASTE_BAND_MAX) {
             const int y = yb + threadIdx.x;
             // normalised y, grid_sample unnormalise (align_corners=False)
             const float gy = ((float)y + 0.5f - by0) / bh * 2.0f - 1.0f;
@@ -182,7 +208,7 @@ __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_ma
 }
 
 // closest[i][jl] for every detection i and every target jl of the same image.  Work item = (mask i,
-// band of CP_BAND window rows); each thread scans its words once per group of 8 targets and keeps 8
+// band of `cb` window rows, picked like the paste launch's); each thread scans its words once per group of 8 targets and keeps 8
 // running minima of (f32 distance bits, row-major index); block minima are merged with atomicMin on
 // 64-bit keys (order-independent) IN the record's `closest` field; the host turns a key into 1-based (x, y) when it
 // has the record (apse_read_results_end).  Prologue (every block, one thread per detection): the band prefix and the
@@ -196,18 +222,24 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
                                                       int* __restrict__ cent_out, int* __restrict__ mass_out) {
     __shared__ int band0[MT_MAXDET + 1];
     __shared__ int cent[MT_MAXDET][2];
+    __shared__ int rowsv[MT_MAXDET];
     __shared__ unsigned long long best[4][8];
     __shared__ int wtot[4];
     const int n = *total < n_max ? *total : n_max;
     const int nd = n < MT_MAXDET ? n : MT_MAXDET;
     for (int i = threadIdx.x; i < nd; i += blockDim.x) {
         const int rows = valid[i] ? rect[i * 4 + 3] - rect[i * 4 + 1] : 0;
-        band0[i] = (rows + CP_BAND - 1) / CP_BAND;
+        band0[i] = rowsv[i] = rows;
         const unsigned long long m = sums[i * 3], sx = sums[i * 3 + 1], sy = sums[i * 3 + 2];
         const int cx = m ? (int)(sx / m) : -1, cy = m ? (int)(sy / m) : -1;
         cent[i][0] = cx; cent[i][1] = cy;
         if (blockIdx.x == 0) { mass_out[i] = (int)m; cent_out[i * 2] = cx; cent_out[i * 2 + 1] = cy; }
     }
+    __syncthreads();
+    mt_scan(band0, nd, wtot);
+    const int cb = mt_pick_band(band0[nd], CP_BAND_MAX, 8, CP_ITEMS_MIN);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) band0[i] = (rowsv[i] + cb - 1) / cb;
     __syncthreads();
     mt_scan(band0, nd, wtot);
     const int nitems = band0[nd];
@@ -219,8 +251,8 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
         const int rx0 = rect[i * 4 + 0], ry0 = rect[i * 4 + 1], rx1 = rect[i * 4 + 2], ry1 = rect[i * 4 + 3];
         const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
         const int nw = w1 - w0;
-        const int yb = ry0 + band * CP_BAND;
-        const int nrows = ((yb + CP_BAND) < ry1 ? (yb + CP_BAND) : ry1) - yb;
+        const int yb = ry0 + band * cb;
+        const int nrows = ((yb + cb) < ry1 ? (yb + cb) : ry1) - yb;
         const uint64_t* bits = bits_all + (size_t)i * out_h * words_per_row;
         for (int jg = j0; jg < j1; jg += 8) {
             float px[8], py[8];

@@ -473,7 +473,10 @@ int apse_k_roi_align(const FpnMaps* F, const float* rois, const int* roi_img, co
     // ~8192 blocks keep the chip's wave slots full: with few rois (batch 1: 1000 proposals, 8 detections) each roi's bins are
     // dealt over several blocks, each of which rebuilds the (cheap) tap tables.  With one block per roi 1000 blocks x 4 waves
     // walk 12 bins each, one after the other: 155 us per frame against 81 us for one wave per bin.
-    int parts = 8192 / blocks;
+#ifndef RA_TARGET_BLOCKS
+#define RA_TARGET_BLOCKS 8192
+#endif
+    int parts = RA_TARGET_BLOCKS / blocks;
     const int max_parts = (R * R + 3) / 4;
     parts = parts < 1 ? 1 : (parts > max_parts ? max_parts : parts);
     if (F->st) hipLaunchKernelGGL(roi_align_nhwc<true>, dim3(blocks, parts), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R, out, out_st);

@@ -35,22 +35,64 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {   // l must 
     return ((uint64_t)hi << 32) | lo;
 }
 
-// Bitonic sort of N (power of two) 64-bit keys in LDS, ascending.  Pair-indexed: every thread
-// owns whole compare-exchange pairs, so no lane idles on the "partner > self" test.
-template <int N, int THREADS>
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int tid) {
+// Bitonic sort of N = 1024 * EPT 64-bit keys in LDS, ascending, by a 1024-thread block.  Thread t owns the EPT consecutive
+// keys a[EPT t ..] in registers: a compare-exchange distance j < EPT stays inside the thread, j < 64 EPT inside the wave
+// (64-bit lane exchange), and only j >= 64 EPT goes through LDS with a block barrier -- 10 of the 78 steps for N = 4096
+// (EPT = 4), 10 of 55 for N = 1024 (EPT = 1).  The all-LDS form paid a barrier per step and ran at ~0.55 us a step with one
+// block per CU (rpn_topk_stage 43 us per 4096 keys).  Same network, same result (the keys are distinct).
+template <int EPT>
+__device__ __forceinline__ void block_bitonic_sort(uint64_t* a, int tid) {
+    constexpr int N = 1024 * EPT;
+    uint64_t e[EPT];
+#pragma unroll
+    for (int s = 0; s < EPT; ++s) e[s] = a[tid * EPT + s];
     for (int k = 2; k <= N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int pidx = tid; pidx < N / 2; pidx += THREADS) {
-                const int i = ((pidx & ~(j - 1)) << 1) | (pidx & (j - 1));
-                const int l = i | j;
-                const bool asc = (i & k) == 0;
-                const uint64_t x = a[i], y = a[l];
-                if ((x > y) == asc) { a[i] = y; a[l] = x; }
-            }
+        int j = k >> 1;
+        if (j >= 64 * EPT) {
+            __syncthreads();                               // every thread has taken its keys out of LDS
+#pragma unroll
+            for (int s = 0; s < EPT; ++s) a[tid * EPT + s] = e[s];
             __syncthreads();
+            for (; j >= 64 * EPT; j >>= 1) {
+                for (int pidx = tid; pidx < N / 2; pidx += 1024) {
+                    const int i = ((pidx & ~(j - 1)) << 1) | (pidx & (j - 1));
+                    const int l = i | j;
+                    const bool asc = (i & k) == 0;
+                    const uint64_t x = a[i], y = a[l];
+                    if ((x > y) == asc) { a[i] = y; a[l] = x; }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int s = 0; s < EPT; ++s) e[s] = a[tid * EPT + s];
+        }
+        for (; j >= EPT; j >>= 1) {                        // partner key lives in lane ^ (j / EPT), same register slot
+            const int tj = j / EPT;
+            const bool lower = (tid & tj) == 0;
+#pragma unroll
+            for (int s = 0; s < EPT; ++s) {
+                const bool asc = ((tid * EPT + s) & k) == 0;
+                const uint64_t o = __shfl_xor(e[s], tj);
+                const bool take_min = lower == asc;
+                e[s] = ((o < e[s]) == take_min) ? o : e[s];
+            }
+        }
+#pragma unroll
+        for (int jj = EPT / 2; jj >= 1; jj >>= 1) {        // both keys in this thread
+            if (jj > (k >> 1)) continue;
+#pragma unroll
+            for (int s = 0; s < EPT; ++s) {
+                if (s & jj) continue;
+                const bool asc = ((tid * EPT + s) & k) == 0;
+                const uint64_t x = e[s], y = e[s | jj];
+                if ((x > y) == asc) { e[s] = y; e[s | jj] = x; }
+            }
         }
     }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < EPT; ++s) a[tid * EPT + s] = e[s];
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------- RPN top-k tournament
@@ -104,7 +146,7 @@ __global__ __launch_bounds__(1024) void rpn_topk_stage(const RpnLevels* __restri
             a[i] = k;
         }
         __syncthreads();
-        bitonic_sort_lds<TK_N, 1024>(a, tid);
+        block_bitonic_sort<TK_N / 1024>(a, tid);
         if (tid < job->dst_count) pool[(size_t)job->dst * 1024 + tid] = a[tid];
     } else {
         const int ns = job->nsrc;
@@ -226,7 +268,7 @@ __global__ __launch_bounds__(1024) void nms_prepare(const float* __restrict__ bo
     // presorted: the entries of a category already come in (score desc, entry asc) order -- the RPN stage, whose entry
     // l * pre_topk + i is rank i of level l's top-k list (sorted by the same key; ties by anchor index = by i) -- so the ordered
     // compaction above IS the sorted list and the 55 barrier steps of the bitonic network are skipped
-    if (!presorted) bitonic_sort_lds<NMS_MAX, 1024>(keys, tid);
+    if (!presorted) block_bitonic_sort<NMS_MAX / 1024>(keys, tid);
     // batched_nms numbers the categories that are present in the call: cat_shift = index of the first one
     const float off = (float)(c - cat_shift) * (__uint_as_float(maxc[b]) + 1.0f);
     float* bx = S.box + slot * 4 * NMS_MAX;
@@ -338,6 +380,8 @@ __global__ __launch_bounds__(1024) void nms_scan(NmsScratch S, int* __restrict__
 // Final ranking by merging: each category's kept list is already sorted by (score desc, entry asc),
 // so the global rank of an element is its own position plus, for every other list, the number of
 // keys that precede it (binary search).  No barriers after the load; first K ranks are written.
+// Grid (image, category): every block loads all lists of its image (the searches need them) and ranks the elements of ITS
+// list -- the ncat x 4 dependent binary searches of one block were 8 of this launch's 21 us at batch 1.
 __global__ __launch_bounds__(1024) void rank_merge(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                    int n_total, const int* __restrict__ keep_idx,
                                                    const int* __restrict__ keep_cnt, int ncat, int K,
@@ -346,23 +390,22 @@ __global__ __launch_bounds__(1024) void rank_merge(const float* __restrict__ box
                                                    uint32_t* __restrict__ zero_word) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);      // [ncat][NMS_MAX]
-    if (zero_word && threadIdx.x == 0) zero_word[blockIdx.x] = 0u;      // next stage's max-coordinate cell
+    const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    if (zero_word && c == 0 && tid == 0) zero_word[b] = 0u;      // next stage's max-coordinate cell
     __shared__ int cnt[8];
-    const int b = blockIdx.x, tid = threadIdx.x;
     boxes += (size_t)b * n_total * 4;
     scores += (size_t)b * n_total;
     if (tid < ncat) cnt[tid] = keep_cnt[b * ncat + tid];
     __syncthreads();
     int total = 0;
-    for (int c = 0; c < ncat; ++c) {
-        const int* src = keep_idx + ((size_t)b * ncat + c) * NMS_MAX;
-        if (tid < cnt[c]) { const int e = src[tid]; keys[c * NMS_MAX + tid] = comp_key(scores[e], (uint32_t)e); }
-        total += cnt[c];
+    for (int o = 0; o < ncat; ++o) {
+        const int* src = keep_idx + ((size_t)b * ncat + o) * NMS_MAX;
+        if (tid < cnt[o]) { const int e = src[tid]; keys[o * NMS_MAX + tid] = comp_key(scores[e], (uint32_t)e); }
+        total += cnt[o];
     }
     __syncthreads();
     const int nout = total < K ? total : K;
-    for (int c = 0; c < ncat; ++c) {
-        if (tid >= cnt[c]) continue;
+    if (tid < cnt[c]) {
         const uint64_t key = keys[c * NMS_MAX + tid];
         int rank = tid;
         for (int o = 0; o < ncat; ++o) {
@@ -380,6 +423,7 @@ __global__ __launch_bounds__(1024) void rank_merge(const float* __restrict__ box
             out_entry[(size_t)b * K + rank] = (int)e;
         }
     }
+    if (c != 0) return;
     for (int i = nout + tid; i < K; i += 1024) {
         float* ob = out_boxes + ((size_t)b * K + i) * 4;
         ob[0] = ob[1] = ob[2] = ob[3] = 0.f;
@@ -523,7 +567,7 @@ int apse_k_rank_final(const float* boxes, const float* scores, int n_total, cons
         done = true;
     }
     if (ncat > 8) return APSE_E_INVALID;
-    hipLaunchKernelGGL(rank_merge, dim3(B), dim3(1024), (size_t)ncat * NMS_MAX * 8, s, boxes, scores, n_total, keep_idx, keep_cnt,
+    hipLaunchKernelGGL(rank_merge, dim3(B, ncat), dim3(1024), (size_t)ncat * NMS_MAX * 8, s, boxes, scores, n_total, keep_idx, keep_cnt,
                        ncat, K, out_boxes, out_scores, out_entry, out_count, zero_word);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }

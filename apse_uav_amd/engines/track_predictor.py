@@ -204,10 +204,10 @@ class TrackPredictor:
 
     def _predict(self, frames, given=None, want_masks=True, upcoming=None, rpn_levels=31, run_ahead=False):
         """``run_ahead`` (callers that do not read the returned feature dict after this call returns -- RcnnTracker.next_frame):
-        when the announced next frame has been staged, its NETWORK is enqueued too, right after this frame's results (and mask
-        windows) have been copied out, so the host-side association of this frame overlaps the GPU work of the next.  The next
-        call then only reads.  Stream order keeps this frame's results copy and window copies in front of everything the next
-        forward overwrites."""
+        when the announced next frame has been staged, its NETWORK is enqueued too, right behind this frame's results copy, so the
+        card goes from one frame to the next without waiting for the host and the host-side association of this frame overlaps the
+        GPU work of the next.  The next call then only reads.  Stream order keeps this frame's results copy in front of everything
+        the next forward overwrites; the mask windows copied out below come from this frame's set of bit planes (two sets alternate)."""
         model = self.model
         rtag = model._running_tag
         if (rtag is not None and given is None and rtag[1] == rpn_levels and len(rtag[0]) == len(frames)
@@ -227,14 +227,18 @@ class TrackPredictor:
         self.prefetch(upcoming)               # host copy + H2D of the next frame while this one computes
         model.read_begin(B)
         self._prestage()                      # ... and its resize, behind this frame's results copy
-        res = model.read_end(B)
-        from ..networks.track_rcnn import LazyFeatures
-        insts = [model.instances_from(res, b, want_masks) for b in range(B)]       # mask windows are copied out here
+        ahead = None
         if run_ahead and given is None and model._input_tag is not None:
+            # ... and its network: nothing in it depends on this frame; the stream keeps this frame's results copy in front of what
+            # the forward overwrites and the library alternates the mask bit planes, so the card never waits for the host to wake up
             nxt = model._input_tag
             model._input_tag = None
             model.run(len(nxt), None, rpn_levels)
-            model._running_tag = (nxt, rpn_levels)
+            ahead = (nxt, rpn_levels)
+        res = model.read_end(B)
+        from ..networks.track_rcnn import LazyFeatures
+        insts = [model.instances_from(res, b, want_masks) for b in range(B)]       # mask windows (of THIS frame) are copied out here
+        model._running_tag = ahead
         return insts, LazyFeatures(model, B)
 
     def __call__(self, original_image, upcoming=None, run_ahead=False):

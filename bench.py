@@ -262,8 +262,9 @@ def main():
     trace = [] if os.environ.get("APSE_BENCH_TRACE") else None      # (submit ms, collect ms) per step -> stderr
     # Single stream, one context (the headline form): the loop is software-pipelined the way TrackPredictor runs it with an announced
     # next frame -- frame i + 1's resize + normalise is enqueued BEHIND frame i's results copy (apse_read_results_begin / _end: the
-    # copy is waited for by event, not the stream), frame i + 1's network is enqueued as soon as frame i's results are on the host, and
-    # the host association + CSV line of frame i run while the GPU already works on frame i + 1.  Every frame's work is inside the
+    # copy is waited for by event, not the stream) and frame i + 1's network right behind that (it needs nothing of frame i; stream order
+    # keeps the copy in front of what it overwrites), so the card never waits for the host; the host association + CSV line of frame i
+    # run while the GPU already works on frame i + 1.  Every frame's work is inside the
     # timed region; nothing runs concurrently on the GPU; results are the same bits (tests/test_gpu_ingest.py).
     fast = depth == 1 and not args.from_host and not args.no_prestage
     if fast:
@@ -291,18 +292,20 @@ def main():
             more = i + 1 < args.steps
             if more:
                 m0.preprocess_frames(frames_of(j + 1))      # behind frame j's network and its results copy
+                ts_next = time.perf_counter()
+                m0.run(B)                                   # frame j + 1's network right behind them: the stream keeps frame j's
+                                                            # results copy in front of everything this forward overwrites, and the
+                                                            # card does not idle while the host wakes up on the copy's event
             res = m0.read_end(B)
             t_ready = time.perf_counter()
-            if more:
-                ts_next = time.perf_counter()
-                m0.run(B)                                   # frame j + 1's network: enqueued before the host work on frame j
             t_post = time.perf_counter()
             post(j, res)
-            # per-frame latency: network enqueued -> results on the host, + this frame's host association / CSV line (which runs
-            # while the GPU is already on the next frame; the resize was staged behind the previous frame: ~40 us not counted)
+            # per-frame latency: from the moment the card is free for this frame (its network was enqueued while the previous frame
+            # was still running, so: the later of that enqueue and the previous frame's results) to its results on the host, + this
+            # frame's host association / CSV line (which runs while the GPU is already on the next frame)
             lat.append((t_ready - ts) + (time.perf_counter() - t_post))
             if more:
-                ts = ts_next
+                ts = max(ts_next, t_ready)
     for i in range(0 if fast else args.steps):     # the timed region carries NO instrumentation (no HIP events, no profiling calls)
         inflight.append((args.warmup + i, time.perf_counter()))
         t_a = time.perf_counter()
@@ -385,8 +388,8 @@ def main():
             "p50_ms_per_frame": round(1000.0 * float(np.median(lat)) / B, 3),
             "config": {"workload": "static synthetic 3840x2160 sequence, batch=%d %s, Mask R-CNN R-%s-FPN, %d GPU(s), "
                                    "frames sharded per rank" % (B, args.dtype, "101" if blocks == (3, 4, 23, 3) else str(blocks), world),
-                       "loop": ("single stream, software-pipelined: next frame's resize behind this frame's results copy, host association "
-                                "overlapped with the next frame's network" if fast else "plain"),
+                       "loop": ("single stream, software-pipelined: next frame's resize and network enqueued behind this frame's results copy, host "
+                                "association overlapped with the next frame's network" if fast else "plain"),
                        "frame": "%dx%d" % (W, H), "preproc": "undistort + gamma fused into the resize" if args.preproc else "none", "batch_per_gpu": B, "frames_in_flight": depth, "proposals_per_frame": P_sum / max(args.steps * B, 1),
                        "detections_per_frame": N_sum / max(args.steps * B, 1),
                        "gflop_per_frame_algorithmic": round(flops_frame / 1e9, 2)},
@@ -485,11 +488,10 @@ def extra_mode(lib, sd, asd, frames, nres, H, W, dev_index, steps, probe_steps, 
         more = i + 1 < steps
         if more:
             model.preprocess_frames(batch_of(warmup + i + 1))
-        res = model.read_end(batch)
-        t_ready = time.perf_counter()
-        if more:
             ts_next = time.perf_counter()
             model.run(batch)
+        res = model.read_end(batch)
+        t_ready = time.perf_counter()
         t_post = time.perf_counter()
         for k in range(batch):
             replay.step(res.record(k), (warmup + i) * batch + k)
@@ -497,7 +499,7 @@ def extra_mode(lib, sd, asd, frames, nres, H, W, dev_index, steps, probe_steps, 
         N += res.total
         lat.append((t_ready - ts) + (time.perf_counter() - t_post))
         if more:
-            ts = ts_next
+            ts = max(ts_next, t_ready)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     nfr = steps * batch

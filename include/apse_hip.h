@@ -146,11 +146,15 @@ int apse_results_describe(apse_ctx* ctx, apse_results_layout* out);
  * rcnn_tracker.py:132 `.cpu()`, mask_utils.py:19,23,38 `.item()`).  = _begin + _end. */
 int apse_read_results(apse_ctx* ctx, void* host_dst, size_t bytes, void* stream);
 /* The same in two halves: _begin enqueues the copy (and an event behind it) and returns; _end waits for that copy only -- work the
- * caller enqueued on the stream in between (the NEXT frame's apse_preprocess_frames: it touches neither the results block nor anything
- * this forward still reads) is not waited for.  host_dst must stay valid and unread until _end returns. */
+ * caller enqueued on the stream in between is not waited for.  That may be the NEXT frame's apse_preprocess_frames AND its whole
+ * forward: nothing in it depends on this frame, stream order keeps this copy in front of everything the forward overwrites, and the
+ * mask bit planes alternate between two sets per forward, so apse_copy_mask_window after _end still reads THIS frame's masks.
+ * host_dst must stay valid and unread until _end returns.  The closest-point table is decoded on the host inside _end (the device
+ * leaves (distance, pixel index) keys in that field). */
 int apse_read_results_begin(apse_ctx* ctx, void* host_dst, size_t bytes, void* stream);
 int apse_read_results_end(apse_ctx* ctx, void* host_dst);
-/* Copies detection i's mask window (rows rect.y0..y1, 64-bit words (x0>>6)..((x1+63)>>6)) to dst_dev. */
+/* Copies detection i's mask window (rows rect.y0..y1, 64-bit words (x0>>6)..((x1+63)>>6)) to dst_dev: the masks of the forward whose
+ * results were last read (apse_read_results / _begin), or of the last forward when no read has been started since. */
 int apse_copy_mask_window(apse_ctx* ctx, int det, int x0, int y0, int x1, int y1, uint64_t* dst_dev, void* stream);
 /* Named internal tensor -> caller buffer as NCHW f32 (p2..p6, res2..res5, stem): the feature dict
  * TrackRCNN.inference returns (track_rcnn.py:57-58).  dims (B,C,H,W) via apse_feature_shape. */
