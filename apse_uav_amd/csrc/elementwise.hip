@@ -31,10 +31,19 @@ __device__ __forceinline__ void pil_stage_row(uint8_t* row, const uint8_t* __res
     const uint8_t* srow = src + (size_t)b * src_img_stride + (size_t)y * W * 3;
     const int nbytes = W * 3;
     if constexpr (FUSED) {
+        // the Lab step is ~15 table look-ups per pixel (14.7 KB of tables): gathers from LDS, not from global memory -- the block
+        // copies the tables once (round 3: the fused horizontal pass was 117 us per 4K frame, most of it those gathers)
+        __shared__ LabTables lab_s;
+        if (cam.do_gamma) {
+            const uint32_t* g = reinterpret_cast<const uint32_t*>(lut);
+            uint32_t* l = reinterpret_cast<uint32_t*>(&lab_s);
+            for (int i = threadIdx.x; i < (int)(sizeof(LabTables) / 4); i += blockDim.x) l[i] = g[i];
+            __syncthreads();
+        }
         const uint8_t* frame = src + (size_t)b * src_img_stride;
         for (int x = threadIdx.x; x < W; x += blockDim.x) {
             int c0, c1, c2;
-            undistort_gamma_pixel(cam, frame, lut, x, y, c0, c1, c2, cam_map);
+            undistort_gamma_pixel(cam, frame, &lab_s, x, y, c0, c1, c2, cam_map);
             row[x * 3 + 0] = (uint8_t)c0; row[x * 3 + 1] = (uint8_t)c1; row[x * 3 + 2] = (uint8_t)c2;
         }
     } else

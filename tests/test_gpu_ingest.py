@@ -38,9 +38,13 @@ def _tracker(env):
 
 
 def _step(tr, frame, t, **kw):
+    """ids, CSV line, packed record bytes, and the bytes of every detection's mask window (copied from the bit planes AFTER the
+    results were read: with an announced frame the next forward is already enqueued by then, and the library's two alternating
+    sets of bit planes must still hand out THIS frame's masks)."""
     from apse_uav_amd.sharding import pack_record
     objs = tr.next_frame(frame, **kw)
-    return (list(objs.ids) if len(objs) else [], tr.log_line(objs, 1, t)[0], pack_record(tr._last_record, 100, 128).tobytes())
+    wins = b"".join(bytes(m.rect.__repr__(), "ascii") + m.window().cpu().numpy().tobytes() for m in objs.pred_masks) if len(objs) else b""
+    return (list(objs.ids) if len(objs) else [], tr.log_line(objs, 1, t)[0], pack_record(tr._last_record, 100, 128).tobytes(), wins)
 
 
 @pytest.fixture(scope="module")
@@ -64,6 +68,7 @@ def test_announced_next_frame_equals_plain(env, plain):
         assert (rt is not None and rt[0][0] is fr[t + 1]) if t + 1 < N else rt is None
     assert [g[2] == p[2] for g, p in zip(got, plain)] == [True] * N
     assert [(g[0], g[1]) for g in got] == [(p[0], p[1]) for p in plain]
+    assert [g[3] == p[3] for g, p in zip(got, plain)] == [True] * N and len({p[3] for p in plain}) == N      # this frame's masks, not the next one's
     # and every prefetch was actually consumed (identity match), not re-uploaded
     assert tr.predictor._prefetched is None and tr.predictor.model._input_tag is None
 
@@ -112,6 +117,7 @@ def test_mutating_the_consumed_frame_buffer_is_safe(env, plain):
         got.append(_step(tr, fr[t], t, upcoming=fr[t + 1] if t + 1 < N else None))
         fr[t][:] = 0                                         # the caller's buffer is its own again
     assert [g[2] == p[2] for g, p in zip(got, plain)] == [True] * N
+    assert [g[3] == p[3] for g, p in zip(got, plain)] == [True] * N
 
 
 def test_start_frame_dynamic_equals_tracker_started_there(env, tmp_path):
