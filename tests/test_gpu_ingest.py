@@ -169,3 +169,17 @@ def test_run_ahead_forward_discarded_when_the_caller_changes_course(env, plain):
     b = _step(tr, fr[1], 1, upcoming=fr[2])
     c = _step(tr, fr[2], 2)
     assert (b[2], c[2]) == (plain[1][2], plain[2][2]) and (b[0], c[0]) == (plain[1][0], plain[2][0])
+
+
+def test_announced_loop_over_a_longer_dynamic_run(env):
+    """24 frames of the dynamic sequence (births, a departure and a return) through next_frame(f_t, upcoming=f_{t+1}) -- every forward
+    enqueued one call ahead, the two sets of mask bit planes alternating 12 times -- against the plain loop: ids, CSV lines, packed
+    records and mask windows of every frame."""
+    from apse_uav_amd.synthetic import SyntheticSequence
+    seq = SyntheticSequence("dynamic", *FRAME)
+    fr = [seq.frame(4 * t) for t in range(24)]
+    a, b = _tracker(env), _tracker(env)
+    for t in range(24):
+        p = _step(a, fr[t], t)
+        g = _step(b, fr[t], t, upcoming=fr[t + 1] if t + 1 < 24 else None)
+        assert g == p, "frame %d differs" % t
