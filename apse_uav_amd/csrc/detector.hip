@@ -25,7 +25,7 @@ struct PasteParams {
 };
 extern "C" {
 int apse_k_pil_resize(const uint8_t*, uint8_t*, void*, int, uint8_t*, const int*, const int*, int, const int*, const int*, int, int,
-                      int, int, int, int, int, int, const float*, const UndistortParams*, const LabTables*, const void*, hipStream_t);
+                      int, int, int, int, int, int, const float*, const UndistortParams*, const LabTables*, const void*, const int*, int, hipStream_t);
 int apse_k_undistort_build_map(const UndistortParams*, void*, hipStream_t);
 int apse_k_chw_norm(const float*, void*, int, int, int, int, int, int, const float*, hipStream_t);
 int apse_k_maxpool3x3s2(const void*, void*, int, int, int, int, int, hipStream_t);
@@ -97,6 +97,8 @@ struct apse_ctx {
     float* ws = nullptr; size_t ws_floats = 0; int* tile_cnt = nullptr;
     // resize tables
     int *hb = nullptr, *hc = nullptr, *vb = nullptr, *vc = nullptr; int hk = 0, vk = 0; uint8_t* rs_tmp = nullptr;
+    int rs_pitch = 0;
+    int* hcT = nullptr;                                  // horizontal taps tap-major [8][image_w], zero past a pixel's count (hk <= 8)
     // rpn
     RpnLevels rl_host; RpnLevels* rl_dev = nullptr;
     std::vector<std::vector<TopkJob>> stages; std::vector<TopkJob*> stage_dev; int nslots = 0; uint64_t* lists = nullptr;
@@ -775,7 +777,8 @@ static int build_plan(apse_ctx* c) {
         if (!c->ws) return fail(c, APSE_E_NOMEM, "split-K workspace alloc");
     }
     c->tile_cnt = dalloc<int>(c, 65536);        // zero-initialised; every launch leaves it zero
-    c->rs_tmp = dalloc<uint8_t>(c, (size_t)B * g.frame_h * g.image_w * 3, false);
+    c->rs_pitch = (g.image_w * 3 + 15) & ~15;            // row pitch of the intermediate image: dword loads in the vertical pass
+    c->rs_tmp = dalloc<uint8_t>(c, (size_t)B * g.frame_h * c->rs_pitch, false);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail(c, APSE_E_HIP, std::string("plan build: ") + hipGetErrorString(e));
     return APSE_OK;
@@ -850,6 +853,13 @@ int apse_set_resize_tables(apse_ctx* c, const int* hb, const int* hc, int hk, co
         if (d[2 * i] < 0 || d[2 * i + 1] > vk || d[2 * i] + d[2 * i + 1] > g.frame_h) return fail(c, APSE_E_INVALID, "bad vertical bounds");
     c->hb = dupload(c, a); c->hc = dupload(c, b); c->vb = dupload(c, d); c->vc = dupload(c, e);
     c->hk = hk; c->vk = vk;
+    c->hcT = nullptr;
+    if (hk <= 8) {
+        std::vector<int> t((size_t)8 * g.image_w, 0);
+        for (int i = 0; i < g.image_w; ++i)
+            for (int j = 0; j < a[2 * i + 1] && j < hk; ++j) t[(size_t)j * g.image_w + i] = b[(size_t)i * hk + j];
+        c->hcT = dupload(c, t);
+    }
     return APSE_OK;
 }
 
@@ -863,7 +873,7 @@ int apse_preprocess_frames(apse_ctx* c, const uint8_t* frames, int batch, void* 
     const apse_config& g = c->cfg;
     int rc = apse_k_pil_resize(frames, c->rs_tmp, c->t["input"].p, c->t["input"].st, nullptr, c->hb, c->hc, c->hk, c->vb, c->vc, c->vk, batch,
                                g.frame_h, g.frame_w, g.image_h, g.image_w, c->PH, c->PW, g.pixel_mean, c->cam_on ? &c->cam : nullptr, c->cam_lut, c->cam_map,
-                               (hipStream_t)stream);
+                               c->hcT, c->rs_pitch, (hipStream_t)stream);
     return rc ? fail(c, rc, "pil resize launch failed") : APSE_OK;
 }
 
@@ -1528,7 +1538,7 @@ int apse_set_camera(apse_ctx* c, const double* m, const double* dist, int ndist,
 int apse_resize_normalize(const uint8_t* frames, uint8_t* tmp, float* out, uint8_t* resized, const int* hb, const int* hc, int hk,
                           const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,
                           const float* mean3, void* stream) {
-    return apse_k_pil_resize(frames, tmp, out, 0, resized, hb, hc, hk, vb, vc, vk, B, H, W, OH, OW, PH, PW, mean3, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    return apse_k_pil_resize(frames, tmp, out, 0, resized, hb, hc, hk, vb, vc, vk, B, H, W, OH, OW, PH, PW, mean3, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 }  // extern "C"

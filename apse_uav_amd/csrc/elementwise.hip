@@ -65,13 +65,13 @@ __global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ 
                                                     const int* __restrict__ bounds, const int* __restrict__ coef,
                                                     int H, int W, int OW, int ksize, size_t src_img_stride,
                                                     size_t tmp_img_stride, const UndistortParams cam, const LabTables* __restrict__ lut,
-                                                    const int2* __restrict__ cam_map) {
+                                                    const int2* __restrict__ cam_map, int tp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint8_t* row = reinterpret_cast<uint8_t*>(smem);
     const int y = blockIdx.x, b = blockIdx.y;
     pil_stage_row<FUSED>(row, src, y, b, W, src_img_stride, cam, lut, cam_map);
     __syncthreads();
-    uint8_t* orow = tmp + (size_t)b * tmp_img_stride + (size_t)y * OW * 3;
+    uint8_t* orow = tmp + (size_t)b * tmp_img_stride + (size_t)y * tp;
     for (int o = threadIdx.x; o < OW * 3; o += blockDim.x) {
         const int ox = o / 3, c = o - ox * 3;
         const int xmin = bounds[2 * ox], cnt = bounds[2 * ox + 1];
@@ -93,11 +93,14 @@ __global__ __launch_bounds__(256) void pil_resize_h8(const uint8_t* __restrict__
                                                      const int2* __restrict__ bounds, const int* __restrict__ coef,
                                                      int H, int W, int OW, int ksize, size_t src_img_stride,
                                                      size_t tmp_img_stride, const UndistortParams cam, const LabTables* __restrict__ lut,
-                                                     const int2* __restrict__ cam_map) {
+                                                     const int2* __restrict__ cam_map, const int* __restrict__ coefT, int tp) {
+    // coefT (optional): the taps tap-major, [8][OW], zero past a pixel's count.  A wave's load of tap j is then 256 consecutive
+    // bytes; pixel-major (coef[ox * ksize + j]) it touches 28 cache lines, and with every block (= source row) re-reading the
+    // whole table that was what paced this pass (TA cycles: 144 us per 8 frames at 1.4 TB/s).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint8_t* row = reinterpret_cast<uint8_t*>(smem);                      // W*3 bytes (+ 32: tap slots past the row end)
     const int y = blockIdx.x, b = blockIdx.y;
-    uint8_t* gdst = tmp + (size_t)b * tmp_img_stride + (size_t)y * OW * 3;
+    uint8_t* gdst = tmp + (size_t)b * tmp_img_stride + (size_t)y * tp;          // tp: row pitch of the intermediate image (>= OW * 3)
     // the output row sits in LDS at the same offset mod 16 as its destination, so the 16-byte body of the copy-out is
     // aligned on both sides whatever OW is (1333 * 3 bytes per row: rows start at every alignment)
     const int mis = (int)(reinterpret_cast<uintptr_t>(gdst) & 15);
@@ -105,6 +108,8 @@ __global__ __launch_bounds__(256) void pil_resize_h8(const uint8_t* __restrict__
     pil_stage_row<FUSED>(row, src, y, b, W, src_img_stride, cam, lut, cam_map);
     if (threadIdx.x < 32) row[W * 3 + threadIdx.x] = 0;
     __syncthreads();
+    // (requesting the taps of all of a thread's pixels before the row is staged -- one round trip instead of four -- was tried:
+    // 133 against 123 us per 8 frames, the 60 extra registers cost more occupancy than the round trips cost time)
     for (int ox0 = threadIdx.x; ox0 < OW; ox0 += 512) {
         int2 bd[2];
         int k[2][8];
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void pil_resize_h8(const uint8_t* __restrict__
             const bool in = ox < OW;
             bd[u] = in ? bounds[ox] : int2{0, 0};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) k[u][j] = (in && j < ksize) ? coef[ox * ksize + j] : 0;
+            for (int j = 0; j < 8; ++j) k[u][j] = !in ? 0 : (coefT ? coefT[j * OW + ox] : (j < ksize ? coef[ox * ksize + j] : 0));
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -158,24 +163,95 @@ __device__ __forceinline__ void input_store(void* out, int out_st, int b, int oy
 }
 
 // Vertical pass + normalise + pad.
+#ifndef PIL_VROWS
+#define PIL_VROWS 4
+#endif
 __global__ __launch_bounds__(256) void pil_resize_v_norm(const uint8_t* __restrict__ tmp, void* __restrict__ out, int out_st,
                                                          const int* __restrict__ bounds, const int* __restrict__ coef,
                                                          int OH, int OW, int ksize, int PH, int PW,
-                                                         float m0, float m1, float m2, size_t tmp_img_stride,
+                                                         float m0, float m1, float m2, size_t tmp_img_stride, int tp,
                                                          uint8_t* __restrict__ resized_u8) {
-    const int oy = blockIdx.y, b = blockIdx.z;
+    // a thread produces its sample column for PIL_VROWS consecutive output rows: their taps (<= 8 each, independent byte loads) are
+    // all requested together -- one block per output row made 12 000 blocks per 4K frame of two dependent round trips each
+    // (90 us per 8 frames, launch- and latency-bound)
+    const int b = blockIdx.z;
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= OW * 3) return;
-    const int ymin = bounds[2 * oy], cnt = bounds[2 * oy + 1];
-    const int* k = coef + oy * ksize;
-    const uint8_t* t = tmp + (size_t)b * tmp_img_stride + (size_t)ymin * OW * 3 + o;
-    int ss = 1 << (PIL_PRECISION_BITS - 1);
-    for (int j = 0; j < cnt; ++j) ss += (int)t[(size_t)j * OW * 3] * k[j];
-    const int v = clip8(ss);
     const int ox = o / 3, c = o - ox * 3;
     const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
-    input_store(out, out_st, b, oy, ox, c, PH, PW, (float)v - mean);
-    if (resized_u8) resized_u8[((size_t)b * OH + oy) * OW * 3 + o] = (uint8_t)v;
+    const uint8_t* tb = tmp + (size_t)b * tmp_img_stride + o;
+    int vv[PIL_VROWS];
+#pragma unroll
+    for (int r = 0; r < PIL_VROWS; ++r) {
+        const int oy = blockIdx.y * PIL_VROWS + r;
+        int ss = 1 << (PIL_PRECISION_BITS - 1);
+        if (oy < OH) {
+            const int ymin = bounds[2 * oy], cnt = bounds[2 * oy + 1];
+            const int* k = coef + oy * ksize;
+            const uint8_t* t = tb + (size_t)ymin * tp;
+            if (ksize <= 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const bool on = j < cnt; ss += (int)t[on ? (size_t)j * tp : 0] * (on ? k[on ? j : 0] : 0); }
+            } else {
+                for (int j = 0; j < cnt; ++j) ss += (int)t[(size_t)j * tp] * k[j];
+            }
+        }
+        vv[r] = clip8(ss);
+    }
+#pragma unroll
+    for (int r = 0; r < PIL_VROWS; ++r) {
+        const int oy = blockIdx.y * PIL_VROWS + r;
+        if (oy >= OH) break;
+        input_store(out, out_st, b, oy, ox, c, PH, PW, (float)vv[r] - mean);
+        if (resized_u8) resized_u8[((size_t)b * OH + oy) * OW * 3 + o] = (uint8_t)vv[r];
+    }
+}
+
+// The same with a 4-byte-aligned row pitch of the intermediate image (the context's own buffer; <= 8 taps): a thread takes FOUR
+// consecutive samples with one dword load per tap.  The byte form issues one 64-byte wave load per tap and sample column and is
+// paced by the texture addresser (70 us per 8 frames at 1.7 TB/s); this one moves the same bytes in a quarter of the loads.
+__global__ __launch_bounds__(256) void pil_resize_v_norm_dw(const uint8_t* __restrict__ tmp, void* __restrict__ out, int out_st,
+                                                            const int* __restrict__ bounds, const int* __restrict__ coef,
+                                                            int OH, int OW, int ksize, int PH, int PW,
+                                                            float m0, float m1, float m2, size_t tmp_img_stride, int tp,
+                                                            uint8_t* __restrict__ resized_u8) {
+    const int b = blockIdx.z;
+    const int o0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (o0 >= OW * 3) return;
+    const uint32_t* tb = reinterpret_cast<const uint32_t*>(tmp + (size_t)b * tmp_img_stride + o0);
+    const int tpw = tp >> 2;
+    int vv[PIL_VROWS][4];
+#pragma unroll
+    for (int r = 0; r < PIL_VROWS; ++r) {
+        const int oy = blockIdx.y * PIL_VROWS + r;
+        int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
+        if (oy < OH) {
+            const int ymin = bounds[2 * oy], cnt = bounds[2 * oy + 1];
+            const int* k = coef + oy * ksize;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool on = j < cnt;
+                const uint32_t w = tb[(size_t)(ymin + (on ? j : 0)) * tpw];
+                const int kk = on ? k[on ? j : 0] : 0;
+                s0 += (int)(w & 0xffu) * kk; s1 += (int)((w >> 8) & 0xffu) * kk; s2 += (int)((w >> 16) & 0xffu) * kk; s3 += (int)(w >> 24) * kk;
+            }
+        }
+        vv[r][0] = clip8(s0); vv[r][1] = clip8(s1); vv[r][2] = clip8(s2); vv[r][3] = clip8(s3);
+    }
+#pragma unroll
+    for (int r = 0; r < PIL_VROWS; ++r) {
+        const int oy = blockIdx.y * PIL_VROWS + r;
+        if (oy >= OH) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = o0 + i;
+            if (o >= OW * 3) break;
+            const int ox = o / 3, c = o - ox * 3;
+            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+            input_store(out, out_st, b, oy, ox, c, PH, PW, (float)vv[r][i] - mean);
+            if (resized_u8) resized_u8[((size_t)b * OH + oy) * OW * 3 + o] = (uint8_t)vv[r][i];
+        }
+    }
 }
 
 // f32 CHW (the reference's model input, track_predictor.py:49) -> normalised padded NHWC4.
@@ -316,8 +392,12 @@ int apse_k_round16(const float* x, uint16_t* y, size_t n, int dtype, hipStream_t
 }
 int apse_k_pil_resize(const uint8_t* src, uint8_t* tmp, void* out, int out_st, uint8_t* resized_u8, const int* hb, const int* hc,
                       int hk, const int* vb, const int* vc, int vk, int B, int H, int W, int OH, int OW, int PH, int PW,
-                      const float* mean, const UndistortParams* cam, const LabTables* lut, const void* cam_map,
+                      const float* mean, const UndistortParams* cam, const LabTables* lut, const void* cam_map, const int* hcT, int tmp_pitch,
                       hipStream_t s) {
+    // tmp_pitch: row pitch of tmp in bytes (0: OW * 3); a multiple of 4 selects the dword vertical pass
+    const int tp = tmp_pitch > 0 ? tmp_pitch : OW * 3;
+    if (tp < OW * 3) return APSE_E_INVALID;
+    // hcT (optional, device): the horizontal taps tap-major [8][OW], zero-filled (apse_set_resize_tables builds it)
     if ((W & 3) != 0 || (size_t)W * 3 > 150000) return APSE_E_INVALID;
     UndistortParams none;
     memset(&none, 0, sizeof none);
@@ -330,18 +410,22 @@ int apse_k_pil_resize(const uint8_t* src, uint8_t* tmp, void* out, int out_st, u
     const int2* map2 = reinterpret_cast<const int2*>(cam_map);
     if (h8 && fused)
         hipLaunchKernelGGL(pil_resize_h8<true>, dim3(H, B), dim3(256), lds8, s, src, tmp, hb2, hc, H, W, OW, hk, (size_t)H * W * 3,
-                           (size_t)H * OW * 3, *cam, lut, map2);
+                           (size_t)H * tp, *cam, lut, map2, hcT, tp);
     else if (h8)
         hipLaunchKernelGGL(pil_resize_h8<false>, dim3(H, B), dim3(256), lds8, s, src, tmp, hb2, hc, H, W, OW, hk, (size_t)H * W * 3,
-                           (size_t)H * OW * 3, none, (const LabTables*)nullptr, (const int2*)nullptr);
+                           (size_t)H * tp, none, (const LabTables*)nullptr, (const int2*)nullptr, hcT, tp);
     else if (fused)
         hipLaunchKernelGGL(pil_resize_h<true>, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
-                           (size_t)H * W * 3, (size_t)H * OW * 3, *cam, lut, map2);
+                           (size_t)H * W * 3, (size_t)H * tp, *cam, lut, map2, tp);
     else
         hipLaunchKernelGGL(pil_resize_h<false>, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
-                           (size_t)H * W * 3, (size_t)H * OW * 3, none, (const LabTables*)nullptr, (const int2*)nullptr);
-    hipLaunchKernelGGL(pil_resize_v_norm, dim3((OW * 3 + 255) / 256, OH, B), dim3(256), 0, s, tmp, out, out_st, vb, vc, OH, OW, vk,
-                       PH, PW, mean[0], mean[1], mean[2], (size_t)H * OW * 3, resized_u8);
+                           (size_t)H * W * 3, (size_t)H * tp, none, (const LabTables*)nullptr, (const int2*)nullptr, tp);
+    if ((tp & 3) == 0 && vk <= 8 && (reinterpret_cast<uintptr_t>(tmp) & 3) == 0)
+        hipLaunchKernelGGL(pil_resize_v_norm_dw, dim3(((OW * 3 + 3) / 4 + 255) / 256, (OH + PIL_VROWS - 1) / PIL_VROWS, B), dim3(256), 0, s, tmp, out,
+                           out_st, vb, vc, OH, OW, vk, PH, PW, mean[0], mean[1], mean[2], (size_t)H * tp, tp, resized_u8);
+    else
+        hipLaunchKernelGGL(pil_resize_v_norm, dim3((OW * 3 + 255) / 256, (OH + PIL_VROWS - 1) / PIL_VROWS, B), dim3(256), 0, s, tmp, out, out_st, vb, vc,
+                           OH, OW, vk, PH, PW, mean[0], mean[1], mean[2], (size_t)H * tp, tp, resized_u8);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_chw_norm(const float* img, void* out, int out_st, int B, int OH, int OW, int PH, int PW, const float* mean, hipStream_t s) {

@@ -586,3 +586,23 @@ def test_4k_fused_bottleneck_equals_three_kernel_form(env, logdir, dtype, monkey
     assert torch.equal(got[0][0].view(torch.int16), got[1][0].view(torch.int16))
     assert torch.equal(got[0][1].view(torch.int16), got[1][1].view(torch.int16))
     assert got[0][2] == got[1][2]
+
+
+def test_4k_context_resize_equals_pillow(env):
+    """The context's own resize path (apse_preprocess_frames: tap-major coefficient table, 16-byte row pitch of the intermediate
+    image, dword vertical pass -- csrc/elementwise.hip) against Pillow itself, batch 2: the network input (f32 NHWC4, mean
+    subtracted, zero padded) must be Pillow's bytes minus the mean, exactly."""
+    from PIL import Image
+    from oracle.detector import resize_shape
+    tr = env["tr"]
+    model = tr.predictor.model
+    frames = [env["seq"].frame(2), env["seq"].frame(13)]
+    model.preprocess_frames(torch.from_numpy(np.stack(frames)).cuda())
+    ih, iw = resize_shape(*FRAME)
+    ph, pw = (ih + 31) // 32 * 32, (iw + 31) // 32 * 32
+    got = model.debug_tensor("input").cpu().view(2, ph, pw, 4)
+    mean = torch.tensor(list(tr.predictor.cfg.MODEL.PIXEL_MEAN), dtype=torch.float32)
+    for b, f in enumerate(frames):
+        ref = torch.from_numpy(np.asarray(Image.fromarray(f).resize((iw, ih), Image.BILINEAR)).astype(np.float32)) - mean
+        assert torch.equal(got[b, :ih, :iw, :3], ref)
+        assert float(got[b, ih:].abs().sum()) == 0.0 and float(got[b, :, iw:].abs().sum()) == 0.0 and float(got[b, ..., 3].abs().sum()) == 0.0
