@@ -12,8 +12,8 @@ a = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     a[r['Kernel_Name'].split('(')[0][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in a.items():
-    if not any(t in k for t in ('conv_igemm', 'conv_glds16', 'conv1x1_stream', 'conv_skinny16', 'stem_s2d_pool16')):
-        continue
+    if '--all' not in sys.argv and not any(t in k for t in ('conv_igemm', 'conv_glds16', 'conv1x1_stream', 'conv_skinny16', 'stem_s2d_pool16')):
+        continue          # default: the convolution kernels; --all: every kernel of the run (the tail between the GEMMs)
     m = {c: sum(x) / len(x) for c, x in v.items()}
     cyc = m['GRBM_GUI_ACTIVE'] / 8.0
     simd_cycles = cyc * 1024
