@@ -58,6 +58,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ApseError("libapse_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "or `make -C apse_uav_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and the library links the system one.  Whichever is
+    # loaded first serves both, and with the system copy first the library found no device on the GPU box once torch had come up
+    # on its own copy afterwards (build() followed by smoke() in one process).  torch first, always.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     sig = {
