@@ -52,41 +52,45 @@ __global__ __launch_bounds__(256) void split_gemm(const float* __restrict__ A, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int srow = tid >> 1, shalf = tid & 1;                 // staging: 2 threads per row, 16 k each
-    const int arow = (m0 + srow) < M ? (m0 + srow) : (M - 1);    // rows past M: computed on a valid row, never stored
-    const float* ag = A + (size_t)arow * K + shalf * 16;
-    const uint16_t* bg = Bp + (size_t)(n0 + srow) * K + shalf * 16;
+    // staging: A as 4 passes of 32 rows x 8 lanes (16 B = 4 k each: a wave instruction reads 8 whole 128-byte row pieces),
+    // B planes as 2 passes of 64 rows x 4 lanes (16 B = 8 k each)
+    const int a_r = tid >> 3, a_s = tid & 7, b_r = tid >> 2, b_s = tid & 3;
+    const float* ag[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + a_r + 32 * q;
+        ag[q] = A + (size_t)(m < M ? m : M - 1) * K + a_s * 4;    // rows past M: computed on a valid row, never stored
+    }
+    const uint16_t* bg = Bp + (size_t)(n0 + b_r) * K + b_s * 8;
     const size_t bplane = (size_t)N * K;
 
     f32x4 ra[4];
     u16x8 rb[3][2];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const f32x4*>(ag + k0 + 4 * q);
+        for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const f32x4*>(ag[q] + k0);
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) rb[p][h] = *reinterpret_cast<const u16x8*>(bg + p * bplane + k0 + 8 * h);
+            for (int h = 0; h < 2; ++h) rb[p][h] = *reinterpret_cast<const u16x8*>(bg + p * bplane + (size_t)(64 * h) * K + k0);
     };
     auto lstore = [&](int buf) {
         char* st = smem + buf * STAGE;
-        u16x8 pa[3][2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+            uint16_t p1[4], p2[4], p3[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                uint16_t p1, p2, p3;
-                split3(ra[q][e], p1, p2, p3);
-                const int idx = q * 4 + e;                      // 0..15 within this thread's 16 k
-                pa[0][idx >> 3][idx & 7] = p1; pa[1][idx >> 3][idx & 7] = p2; pa[2][idx >> 3][idx & 7] = p3;
-            }
+            for (int e = 0; e < 4; ++e) split3(ra[q][e], p1[e], p2[e], p3[e]);
+            const uint32_t off = swz(a_r + 32 * q, a_s >> 1) + (a_s & 1) * 8;       // 4 k = 8 bytes: half a 16-byte slot
+            typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u16x4*>(st + 0 * PLANE + off) = u16x4{p1[0], p1[1], p1[2], p1[3]};
+            *reinterpret_cast<u16x4*>(st + 1 * PLANE + off) = u16x4{p2[0], p2[1], p2[2], p2[3]};
+            *reinterpret_cast<u16x4*>(st + 2 * PLANE + off) = u16x4{p3[0], p3[1], p3[2], p3[3]};
+        }
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                *reinterpret_cast<u16x8*>(st + p * PLANE + swz(srow, shalf * 2 + h)) = pa[p][h];
-                *reinterpret_cast<u16x8*>(st + (3 + p) * PLANE + swz(srow, shalf * 2 + h)) = rb[p][h];
-            }
+            for (int h = 0; h < 2; ++h) *reinterpret_cast<u16x8*>(st + (3 + p) * PLANE + swz(b_r + 64 * h, b_s)) = rb[p][h];
     };
 
     f32x16 acc[2][2];
