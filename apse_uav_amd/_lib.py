@@ -113,7 +113,7 @@ def load():
         "apse_replay_create": ([i, i, f, i], vp),
         "apse_replay_destroy": ([vp], None),
         "apse_replay_step": ([vp, i, i, vp, vp, vp, C.c_char_p, i, vp], i),
-        "apse_replay_packed": ([vp, vp, i, i, i, i, vp, C.c_longlong], C.c_longlong),
+        "apse_replay_packed": ([vp, vp, C.c_longlong, i, i, i, vp, C.c_longlong], C.c_longlong),
         "apse_replay_max_id": ([vp], i),
         "apse_replay_next_id": ([vp], i),
         "apse_resize_normalize": ([vp, vp, vp, vp, vp, vp, i, vp, vp, i, i, i, i, i, i, i, i, C.POINTER(f * 3), vp], i),

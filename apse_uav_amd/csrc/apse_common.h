@@ -53,7 +53,6 @@ struct ConvParams {
 // implicit-GEMM kernel itself (a split-K reduce pass, if any, follows ev1).
 int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk);
-int apse_launch_conv_bf16(const ConvParams& p, int cfg, hipStream_t s);   // conv_igemm_bf16.hip
 // conv1x1_stream.hip: the memory-streaming kernel for small-K / wide-N 1x1 layers (cfg label APSE_CFG_STREAM in profiles)
 #define APSE_CFG_STREAM 9
 #define APSE_CFG_BNECK 10            // bottleneck16.hip: a whole 64-channel bottleneck (conv1 + conv2 + conv3 + residual) in one launch (profile label only)

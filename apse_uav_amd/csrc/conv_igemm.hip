@@ -33,8 +33,9 @@
 // PR = 0: f32 operands (v_mfma_f32_32x32x2_f32).  PR = 1 / 2: bf16 / f16 operands already STORED in that type
 // (activations x_st == PR, filters pre-rounded in w16; v_mfma_f32_32x32x16_*): an LDS row is then 64 elements = the same
 // 128 bytes, a staged piece the same 16 bytes, so the staging, swizzle and epilogue are shared; only the element
-// count per k sub-step (64 instead of 32) and the MFMA issue differ.  (16-bit operands that must be converted from f32
-// at staging -- the stem -- and filter rows that are not a multiple of 64 elements stay on conv_igemm_bf16.hip.)
+// count per k sub-step (64 instead of 32) and the MFMA issue differ.  (Round 4: the older kernel that converted f32-stored
+// activations to 16-bit operands while staging -- conv_igemm_bf16.hip -- is gone: no BASELINE configuration stores f32 and
+// multiplies in 16 bits; such a request is refused.)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 apse_mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 apse_mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -667,7 +668,7 @@ static int launch_cfg_k2(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hip
 }
 
 // 16-bit operands already stored in the operand type, filter rows a whole number of 64-element steps: the scheduled kernel's
-// shape for tile config `cfg` (0 128x128, 1 64x64, 3 128x64, 6 64x64 8 waves, 8 256x128), or -1 (legacy conv_igemm_bf16 path)
+// shape for tile config `cfg` (0 128x128, 1 64x64, 3 128x64, 6 64x64 8 waves, 8 256x128), or -1 (not eligible: refused)
 static int fast16_shape(const ConvParams& p, int cfg) {
     const bool fast16 = (p.prec == 1 || p.prec == 2) && p.w16 && p.x_st == p.prec && (p.KWCp & 63) == 0 && p.cin_log2 >= 3 &&
                         ((((size_t)p.B * p.H * p.W) << p.cin_log2) * 2 < 0xfffffff0ull) && !p.tile_cnt;
@@ -720,16 +721,8 @@ int apse_launch_conv(const ConvParams& p, int cfg, hipStream_t s, hipEvent_t ev0
             }
             return rc;              // launch_cfg_x adds the split-K reduce pass itself
         }
-        if (ev0) hipEventRecord(ev0, s);
-        int rc = apse_launch_conv_bf16(p, cfg, s);
-        if (ev1) hipEventRecord(ev1, s);
-        if (rc == APSE_OK && p.splitk > 1 && !p.tile_cnt) {
-            const size_t total = (size_t)p.M * p.Cout;
-            int blocks = (int)((total + 255) / 256);
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(conv_splitk_reduce, dim3(blocks), dim3(256), 0, s, p);
-        }
-        return rc;
+        // 16-bit operands need 16-bit STORED activations, filter rows of whole 64-element steps and the separate reduce pass
+        return APSE_E_INVALID;
     }
     switch (cfg) {
         case 0: return launch_cfg<2, 2, 2, 2, 1>(p, s, ev0, ev1);

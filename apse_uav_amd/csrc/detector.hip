@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -66,6 +67,7 @@ int apse_k_dense_to_bits(const uint8_t*, int, int, int, uint64_t*, unsigned long
 
 static std::string g_create_error;
 #define NMS_SLOT 1024
+#define APSE_EV_HALF 1024    // HIP events per half of the profiling pool (one pair per timed launch)
 #define APSE_EXPECTED_DETS 8      // list length the packed-list GEMMs are shaped for (static: see add_conv)
 
 struct HostW { std::vector<float> v; std::vector<int64_t> shape; };
@@ -114,7 +116,7 @@ struct apse_ctx {
     apse_results_layout lay; uint8_t* res = nullptr;
     // mask tail
     uint64_t* bits2[2] = {nullptr, nullptr}; int bits_cur = 0, bits_read = 0;   // mask bit planes, alternating per forward (see apse_mask_tail)
-    unsigned long long* sums = nullptr; int wpr = 0;
+    unsigned long long* sums = nullptr; int wpr = 0; bool sums_dirty = false;
     float* emb_raw = nullptr;
     float* ws_assoc = nullptr;      // [K / 128][max detections][embed_dim]: K slices of the association FC (apse_k_assoc_fc), or nullptr
     float* rf_mask = nullptr; size_t rf_mask_floats = 0;      // apse_roi_features: masks at p2 resolution (grown on demand)
@@ -122,10 +124,16 @@ struct apse_ctx {
     UndistortParams cam; bool cam_on = false; LabTables* cam_lut = nullptr; void* cam_map = nullptr;     // apse_set_camera: fused undistort + gamma in apse_preprocess_frames
     int hint_total = 8;      // detections seen in the previous forward: sizes the GRID of the packed-list GEMMs, nothing else
     hipEvent_t read_ev = nullptr; void* read_pending = nullptr;      // apse_read_results_begin / _end
+    // apse_set_detections: two pinned staging blocks, each guarded by the event behind its H2D copies, so the call only enqueues
+    // (a sequence driver puts the next given-boxes forward behind apse_read_results_begin like any other forward)
+    uint8_t* given_host[2] = {nullptr, nullptr}; hipEvent_t given_ev[2] = {nullptr, nullptr}; int given_k = 0;
     // per-kernel profiling with HIP events on the caller's stream (bench.py roofline)
     bool prof_on = false; std::vector<hipEvent_t> ev_pool; int ev_used = 0;
     struct Pending { int cfg; double flops_per_item; int count_kind; int b_mult; int batch; int e0, e1; };
     std::vector<Pending> pending; double prof[APSE_NCFG][3] = {{0}};
+    // the event pool has two halves: apse_read_results_begin hands the half (and the pending list) of the forward it reads to _end
+    // and switches recording to the other half, so a forward enqueued between the two halves of a read keeps its own events
+    int ev_base = 0, cal_read = -1; std::vector<Pending> pending_read;
     // stateless-op scratch
     uint64_t* op_bits = nullptr; unsigned long long* op_sums = nullptr; size_t op_bits_words = 0;
 };
@@ -413,11 +421,11 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
             if (c->prof_on && c->ev_used == 0) {
                 // calibration pair: two back-to-back records; their elapsed time (the marker overhead a timed
                 // kernel also pays) is subtracted from every measurement of this forward
-                hipEventRecord(c->ev_pool[0], s);
-                hipEventRecord(c->ev_pool[1], s);
+                hipEventRecord(c->ev_pool[c->ev_base], s);
+                hipEventRecord(c->ev_pool[c->ev_base + 1], s);
                 c->ev_used = 2;
             }
-            if (c->prof_on && c->ev_used + 2 <= (int)c->ev_pool.size()) { e0 = c->ev_used; c->ev_used += 2; }
+            if (c->prof_on && c->ev_used + 2 <= APSE_EV_HALF) { e0 = c->ev_base + c->ev_used; c->ev_used += 2; }
             if (st.c.pool_y) {
                 rc = apse_k_stem_pool16(p.x, p.w16, p.bias, st.c.pool_y, batch, p.H, p.W, p.prec, s, e0 >= 0 ? c->ev_pool[e0] : nullptr,
                                         e0 >= 0 ? c->ev_pool[e0 + 1] : nullptr);
@@ -430,11 +438,11 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
         } else if (st.kind == S_BNECK) {
             int e0 = -1;
             if (c->prof_on && c->ev_used == 0) {
-                hipEventRecord(c->ev_pool[0], s);
-                hipEventRecord(c->ev_pool[1], s);
+                hipEventRecord(c->ev_pool[c->ev_base], s);
+                hipEventRecord(c->ev_pool[c->ev_base + 1], s);
                 c->ev_used = 2;
             }
-            if (c->prof_on && c->ev_used + 2 <= (int)c->ev_pool.size()) { e0 = c->ev_used; c->ev_used += 2; }
+            if (c->prof_on && c->ev_used + 2 <= APSE_EV_HALF) { e0 = c->ev_base + c->ev_used; c->ev_used += 2; }
             const ConvParams& q1 = st.c.p;
             rc = apse_k_bottleneck64_fused16(st.x, st.p3.res, st.y, q1.w16, q1.bias, st.p2.w16, st.p2.bias, st.p3.w16, st.p3.bias, batch,
                                              st.H, st.W, st.C, st.st, s, e0 >= 0 ? c->ev_pool[e0] : nullptr, e0 >= 0 ? c->ev_pool[e0 + 1] : nullptr);
@@ -790,7 +798,7 @@ extern "C" {
 #ifndef APSE_SRC_HASH
 #define APSE_SRC_HASH "unknown"
 #endif
-const char* apse_version(void) { return "apse_hip 0.5 (gfx950, f32 / bf16 / f16 MFMA) src " APSE_SRC_HASH; }
+const char* apse_version(void) { return "apse_hip 0.6 (gfx950, f32 / bf16 / f16 MFMA) src " APSE_SRC_HASH; }
 
 int apse_create(const apse_config* cfg, apse_ctx** out) {
     if (!cfg || !out) return fail(nullptr, APSE_E_INVALID, "null argument");
@@ -799,6 +807,9 @@ int apse_create(const apse_config* cfg, apse_ctx** out) {
         cfg->dets_per_image > 100 || cfg->num_classes < 1 || cfg->num_classes > 6 || cfg->embed_dim > 256 ||
         (cfg->frame_w & 3) != 0 || cfg->max_batch * cfg->dets_per_image > 1024)
         return fail(nullptr, APSE_E_INVALID, "config out of supported range");
+    if (cfg->compute_dtype < 0 || cfg->compute_dtype > 2 || (cfg->compute_dtype && !cfg->storage16))
+        return fail(nullptr, APSE_E_INVALID, "compute_dtype 1 / 2 (bf16 / f16 matrix cores) needs storage16 = 1: the f32-storage variant "
+                                             "of the 16-bit modes was removed in round 4 (no BASELINE configuration uses it)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, APSE_E_HIP, "no HIP device visible: the apse_uav hot path has no CPU fallback");
@@ -815,6 +826,10 @@ void apse_destroy(apse_ctx* c) {
     for (void* p : c->allocs) hipFree(p);
     if (c->rf_mask) hipFree(c->rf_mask);
     if (c->read_ev) hipEventDestroy(c->read_ev);
+    for (int k = 0; k < 2; ++k) {
+        if (c->given_ev[k]) hipEventDestroy(c->given_ev[k]);
+        if (c->given_host[k]) hipHostFree(c->given_host[k]);
+    }
     delete c;
 }
 
@@ -924,6 +939,7 @@ int apse_rpn(apse_ctx* c, int batch, void* stream) { return apse_rpn_levels(c, b
 static int pack_from_dets(apse_ctx* c, int batch, hipStream_t s) {
     const apse_config& g = c->cfg;
     uint8_t* r = c->res;
+    c->sums_dirty = false;                 // pack_detections clears the integer sums of the mask tail
     return apse_k_pack_detections(c->det_boxes, c->det_scores, c->det_entry, c->det_cnt, batch, g.dets_per_image, g.num_classes,
                                   (float*)(r + c->lay.box_resized), (float*)(r + c->lay.score), (int*)(r + c->lay.cls),
                                   (int*)(r + c->lay.img), (int*)(r + c->lay.roi), (int*)(r + c->lay.total),
@@ -964,8 +980,22 @@ int apse_set_detections(apse_ctx* c, const float* boxes, const int* classes, con
     hipStream_t s = (hipStream_t)stream;
     const apse_config& g = c->cfg;
     const int KD = g.dets_per_image, K = g.num_classes;
-    std::vector<float> db((size_t)batch * KD * 4, 0.f), ds((size_t)batch * KD, 0.f);
-    std::vector<int> de((size_t)batch * KD, -1), dc(batch, 0);
+    const size_t nb = (size_t)g.max_batch * KD;
+    const size_t bytes = nb * 16 + nb * 4 + nb * 4 + (size_t)g.max_batch * 4;
+    const int slot = c->given_k ^= 1;
+    if (!c->given_host[slot]) {
+        HIPCHK(c, hipHostMalloc((void**)&c->given_host[slot], bytes, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&c->given_ev[slot], hipEventDisableTiming));
+    } else {
+        HIPCHK(c, hipEventSynchronize(c->given_ev[slot]));       // the copies of the call before last have left this block
+    }
+    float* db = (float*)c->given_host[slot];
+    float* ds = db + nb * 4;
+    int* de = (int*)(ds + nb);
+    int* dc = de + nb;
+    memset(db, 0, nb * 16 + nb * 4);
+    for (size_t i = 0; i < nb; ++i) de[i] = -1;
+    for (int b = 0; b < g.max_batch; ++b) dc[b] = 0;
     int o = 0;
     for (int b = 0; b < batch; ++b) {
         if (counts[b] < 0 || counts[b] > KD) return fail(c, APSE_E_INVALID, "too many given detections");
@@ -977,11 +1007,12 @@ int apse_set_detections(apse_ctx* c, const float* boxes, const int* classes, con
             de[(size_t)b * KD + k] = k * K + classes[o];      // entry % K = class; entry / K = local index
         }
     }
-    HIPCHK(c, hipMemcpyAsync(c->det_boxes, db.data(), db.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->det_scores, ds.data(), ds.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->det_entry, de.data(), de.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->det_cnt, dc.data(), dc.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipStreamSynchronize(s));                         // host vectors die at return
+    const size_t nbb = (size_t)batch * KD;
+    HIPCHK(c, hipMemcpyAsync(c->det_boxes, db, nbb * 16, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->det_scores, ds, nbb * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->det_entry, de, nbb * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->det_cnt, dc, (size_t)batch * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipEventRecord(c->given_ev[slot], s));
     int rc = pack_from_dets(c, batch, s);
     return rc ? fail(c, rc, "pack launch failed") : APSE_OK;
 }
@@ -1007,6 +1038,10 @@ int apse_mask_tail(apse_ctx* c, int batch, void* stream) {
     // Two sets of bit planes, alternating per forward: a caller may enqueue the NEXT forward right behind apse_read_results_begin
     // (nothing in it depends on this one) and still copy this forward's mask windows out afterwards (apse_copy_mask_window reads
     // the set that belongs to the results last read).
+    // the integer sums paste_masks adds into are cleared by pack_detections (apse_box_head / apse_set_detections); a caller that
+    // repeats apse_mask_tail on one detection list (a timing loop) gets them cleared here, so the call is idempotent
+    if (c->sums_dirty) HIPCHK(c, hipMemsetAsync(c->sums, 0, (size_t)g.max_batch * g.dets_per_image * 3 * sizeof(unsigned long long), s));
+    c->sums_dirty = true;
     c->bits_cur ^= 1;
     if (!c->read_pending) c->bits_read = c->bits_cur;
     uint64_t* bits = c->bits2[c->bits_cur];
@@ -1070,6 +1105,13 @@ int apse_read_results_begin(apse_ctx* c, void* host_dst, size_t bytes, void* str
     HIPCHK(c, hipEventRecord(c->read_ev, (hipStream_t)stream));
     c->read_pending = host_dst;
     c->bits_read = c->bits_cur;                  // the mask windows that belong to these results
+    if (c->prof_on) {                            // this forward's event pairs go to _end; the next forward records into the other half
+        c->pending_read.swap(c->pending);
+        c->pending.clear();
+        c->cal_read = c->ev_used >= 2 ? c->ev_base : -1;
+        c->ev_base ^= APSE_EV_HALF;
+        c->ev_used = 0;
+    }
     return APSE_OK;
 }
 
@@ -1102,8 +1144,8 @@ int apse_read_results_end(apse_ctx* c, void* host_dst) {
         const int total = *reinterpret_cast<const int*>(h + c->lay.total);
         const int* pc = reinterpret_cast<const int*>(h + c->lay.prop_count);
         float cal = 0.f;
-        if (c->ev_used >= 2 && hipEventElapsedTime(&cal, c->ev_pool[0], c->ev_pool[1]) != hipSuccess) cal = 0.f;
-        for (auto& q : c->pending) {
+        if (c->cal_read >= 0 && hipEventElapsedTime(&cal, c->ev_pool[c->cal_read], c->ev_pool[c->cal_read + 1]) != hipSuccess) cal = 0.f;
+        for (auto& q : c->pending_read) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, c->ev_pool[q.e0], c->ev_pool[q.e1]) != hipSuccess) continue;
             ms = ms > cal ? ms - cal : ms;
@@ -1112,8 +1154,8 @@ int apse_read_results_end(apse_ctx* c, void* host_dst) {
             else if (q.count_kind == 2) items = total;
             c->prof[q.cfg][0] += ms; c->prof[q.cfg][1] += q.flops_per_item * items; c->prof[q.cfg][2] += 1;
         }
-        c->pending.clear();
-        c->ev_used = 0;
+        c->pending_read.clear();
+        c->cal_read = -1;
     }
     return APSE_OK;
 }
@@ -1126,11 +1168,13 @@ int apse_read_results(apse_ctx* c, void* host_dst, size_t bytes, void* stream) {
 int apse_profile(apse_ctx* c, int enable) {
     if (!c) return APSE_E_INVALID;
     if (enable && c->ev_pool.empty()) {
-        c->ev_pool.resize(1024);
+        c->ev_pool.resize(2 * APSE_EV_HALF);
         for (auto& e : c->ev_pool) if (hipEventCreate(&e) != hipSuccess) return fail(c, APSE_E_HIP, "hipEventCreate");
     }
     c->prof_on = enable != 0;
     c->pending.clear();
+    c->pending_read.clear();
+    c->cal_read = -1;
     c->ev_used = 0;
     return APSE_OK;
 }
@@ -1470,20 +1514,26 @@ static int fill_camera(UndistortParams& p, int H, int W, const double* m, const 
     return APSE_OK;
 }
 
-// Lab tables of a gamma LUT, device-resident for the stateless operator (rebuilt when the LUT changes; the operator is a
-// test / tool entry, a context keeps its own copy)
+// Lab tables of a gamma LUT, device-resident for the stateless operator: one copy PER DEVICE (keyed by hipGetDevice), rebuilt
+// when the LUT changes, guarded by a mutex (the operator is a test / tool entry; a context keeps its own copy)
 static int lab_tables_device(const uint8_t* lut, hipStream_t s, LabTables** out) {
-    static LabTables* dev = nullptr;
+    struct PerDev { LabTables* dev = nullptr; uint8_t lut[256]; bool have = false; };
+    static std::mutex mu;
+    static std::map<int, PerDev> cache;
     static LabTables host;
-    static bool have = false;
-    if (!dev && hipMalloc(reinterpret_cast<void**>(&dev), sizeof(LabTables)) != hipSuccess) return APSE_E_NOMEM;
-    if (!have || memcmp(host.lut, lut, 256) != 0) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return APSE_E_HIP;
+    std::lock_guard<std::mutex> lock(mu);
+    PerDev& e = cache[device];
+    if (!e.dev && hipMalloc(reinterpret_cast<void**>(&e.dev), sizeof(LabTables)) != hipSuccess) return APSE_E_NOMEM;
+    if (!e.have || memcmp(e.lut, lut, 256) != 0) {
         hipStreamSynchronize(s);                       // an earlier launch may still read the previous tables
         lab_tables_build(&host, lut);
-        if (hipMemcpy(dev, &host, sizeof(LabTables), hipMemcpyHostToDevice) != hipSuccess) return APSE_E_HIP;
-        have = true;
+        if (hipMemcpy(e.dev, &host, sizeof(LabTables), hipMemcpyHostToDevice) != hipSuccess) return APSE_E_HIP;
+        memcpy(e.lut, lut, 256);
+        e.have = true;
     }
-    *out = dev;
+    *out = e.dev;
     return APSE_OK;
 }
 

@@ -197,35 +197,38 @@ int apse_replay_step(apse_replay* r, int frame_idx, int n, const float* emb, con
     return replay_step(r, frame_idx, n, emb, cent, closest, n, line, cap, det_ids);
 }
 
-// Replays `nrec` records in the wire format of apse_uav_amd/sharding.py::pack_record (f32 vectors of `stride`
-// floats: [0] = n, then boxes, scores, classes, centroids, mass, rects (kd rows each), closest [kd][kd][2],
-// embeddings [kd][edim]).  Lines are written NUL-free, separated by '\n', into out[0..cap); returns the number
-// of bytes written or a negative code.
-long long apse_replay_packed(apse_replay* r, const float* recs, int nrec, int stride, int kd, int first_frame, char* out,
+// Replays `nrec` records laid end to end in the wire format of apse_uav_amd/sharding.py::pack_record (count-prefixed f32
+// vectors: [0] = n, then boxes [n][4], scores [n], classes [n], centroids [n][2], mass [n], rects [n][4], closest [n][n][2],
+// embeddings [n][edim]; `total` floats in all).  Lines are written NUL-free, separated by '\n', into out[0..cap); returns the
+// number of bytes written or a negative code.
+long long apse_replay_packed(apse_replay* r, const float* recs, long long total, int nrec, int kd, int first_frame, char* out,
                              long long cap) {
-    if (!r || !recs || !out || nrec < 0) return APSE_E_INVALID;
+    if (!r || (!recs && total > 0) || !out || nrec < 0 || total < 0) return APSE_E_INVALID;
     const int E = r->edim;
-    const int o_cent = 1 + kd * 4 + kd + kd, o_clos = o_cent + kd * 2 + kd + kd * 4, o_emb = o_clos + kd * kd * 2;
-    if (o_emb + kd * E > stride) return APSE_E_INVALID;
-    std::vector<int> cent((size_t)kd * 2), clos((size_t)kd * kd * 2);
+    std::vector<int> cent, clos;
     std::vector<char> line(1 << 16);
-    long long w = 0;
+    long long w = 0, o = 0;
     for (int k = 0; k < nrec; ++k) {
-        const float* v = recs + (size_t)k * stride;
+        if (o >= total) return APSE_E_INVALID;
+        const float* v = recs + o;
         const int n = (int)v[0];
         if (n < 0 || n > kd) return APSE_E_INVALID;
-        for (int i = 0; i < n * 2; ++i) cent[i] = (int)v[o_cent + i];
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) {
-                clos[((size_t)i * kd + j) * 2] = (int)v[o_clos + ((size_t)i * kd + j) * 2];
-                clos[((size_t)i * kd + j) * 2 + 1] = (int)v[o_clos + ((size_t)i * kd + j) * 2 + 1];
-            }
-        const int len = replay_step(r, first_frame + k, n, v + o_emb, cent.data(), clos.data(), kd, line.data(), (int)line.size(), nullptr);
+        const long long len_rec = 1 + (long long)n * 13 + (long long)n * n * 2 + (long long)n * E;
+        if (o + len_rec > total) return APSE_E_INVALID;
+        const float* vc = v + 1 + n * 6;                 // behind boxes, scores, classes
+        const float* vl = v + 1 + n * 13;
+        cent.resize((size_t)n * 2 + 1);
+        clos.resize((size_t)n * n * 2 + 1);
+        for (int i = 0; i < n * 2; ++i) cent[i] = (int)vc[i];
+        for (int i = 0; i < n * n * 2; ++i) clos[i] = (int)vl[i];
+        const int len = replay_step(r, first_frame + k, n, vl + (size_t)n * n * 2, cent.data(), clos.data(), n, line.data(),
+                                    (int)line.size(), nullptr);
         if (len < 0) return len;
         if (w + len + 1 > cap) return APSE_E_INVALID;
         memcpy(out + w, line.data(), len);
         w += len;
         out[w++] = '\n';
+        o += len_rec;
     }
     return w;
 }

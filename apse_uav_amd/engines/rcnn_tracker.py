@@ -112,38 +112,37 @@ class RcnnTracker:
         return torch.cuda.stream(self._assoc_stream)
 
     def _associate(self, detections, backbone_features):
-        if True:
-            rec = getattr(detections, "_record", None)
-            if rec is not None:
-                # embeddings already computed by the fused GPU stage; kept on the host: the sequential
-                # association (this method) is host work, also on rank 0 of a sharded run
-                detection_embeddings = torch.from_numpy(np.ascontiguousarray(rec["embeddings"]))
-                if not getattr(self, "_host_replay", False):
-                    detection_embeddings = detection_embeddings.to(self.device)     # next_frame: distance matrix on the GPU
-            else:
-                rois = self.get_features_rois(detections, backbone_features, crop_features=self.crop_features)
-                detection_embeddings = self.association_head(rois)
-            if len(self.objects) == 0:
-                for detection_id in range(len(detections)):
+        rec = getattr(detections, "_record", None)
+        if rec is not None:
+            # embeddings already computed by the fused GPU stage; kept on the host: the sequential
+            # association (this method) is host work, also on rank 0 of a sharded run
+            detection_embeddings = torch.from_numpy(np.ascontiguousarray(rec["embeddings"]))
+            if not getattr(self, "_host_replay", False):
+                detection_embeddings = detection_embeddings.to(self.device)     # next_frame: distance matrix on the GPU
+        else:
+            rois = self.get_features_rois(detections, backbone_features, crop_features=self.crop_features)
+            detection_embeddings = self.association_head(rois)
+        if len(self.objects) == 0:
+            for detection_id in range(len(detections)):
+                self.objects.add_new_object(detection_id, detections, detection_embeddings)
+                self._obj_det[self.objects.ids[-1]] = detection_id
+        else:
+            distances = self.calculate_distance_matrix(detection_embeddings)
+            dist_np = distances.cpu().detach().numpy()
+            match_obj_indexes, match_det_indexes = linear_sum_assignment(dist_np)
+            matched_detections = []
+            for obj_idx, det_idx in zip(match_obj_indexes, match_det_indexes):
+                if 'hungarian_matches' in self.DISPLAY_INFO: print('obj {} to det {}'.format(obj_idx, det_idx))
+                obj_idx = int(obj_idx)
+                det_idx = int(det_idx)
+                if dist_np[obj_idx, det_idx] < self.ASSOCIATION_EMBEDDING_THRESHOLD:
+                    self.objects.associate_detection(det_idx, obj_idx, detections, detection_embeddings)
+                    self._obj_det[self.objects.ids[obj_idx]] = det_idx
+                    matched_detections.append(det_idx)
+            for detection_id in range(len(detections)):
+                if detection_id not in matched_detections:
                     self.objects.add_new_object(detection_id, detections, detection_embeddings)
                     self._obj_det[self.objects.ids[-1]] = detection_id
-            else:
-                distances = self.calculate_distance_matrix(detection_embeddings)
-                dist_np = distances.cpu().detach().numpy()
-                match_obj_indexes, match_det_indexes = linear_sum_assignment(dist_np)
-                matched_detections = []
-                for obj_idx, det_idx in zip(match_obj_indexes, match_det_indexes):
-                    if 'hungarian_matches' in self.DISPLAY_INFO: print('obj {} to det {}'.format(obj_idx, det_idx))
-                    obj_idx = int(obj_idx)
-                    det_idx = int(det_idx)
-                    if dist_np[obj_idx, det_idx] < self.ASSOCIATION_EMBEDDING_THRESHOLD:
-                        self.objects.associate_detection(det_idx, obj_idx, detections, detection_embeddings)
-                        self._obj_det[self.objects.ids[obj_idx]] = det_idx
-                        matched_detections.append(det_idx)
-                for detection_id in range(len(detections)):
-                    if detection_id not in matched_detections:
-                        self.objects.add_new_object(detection_id, detections, detection_embeddings)
-                        self._obj_det[self.objects.ids[-1]] = detection_id
 
     def reset_tracker(self):
         self.objects = ObjectInstances(image_size=self.image_size, display_info=self.DISPLAY_INFO)

@@ -130,14 +130,31 @@ class NativeReplay:
             raise RuntimeError("apse_replay_step failed (%d)" % rc)
         return self._buf.value.decode(), sorted(int(v) for v in ids[:n] if v > 0)
 
-    def run_packed(self, packed, kd, first_frame=0):
-        """packed: float32 array [nrec, record_len] in the gather's wire format -> list of CSV lines."""
-        packed = np.ascontiguousarray(packed, np.float32)
-        nrec, stride = packed.shape
-        cap = max(1 << 16, nrec * (64 + 48 * max(self.max_id + kd, 8)))
-        buf = self._C.create_string_buffer(cap)
-        w = self._lib.apse_replay_packed(self._h, packed.ctypes.data, nrec, stride, int(kd), int(first_frame), buf, cap)
-        if w < 0:
-            raise RuntimeError("apse_replay_packed failed (%d)" % w)
-        text = buf.raw[:w].decode()
-        return text.split("\n")[:-1] if nrec else []
+    def run_packed(self, packed, nrec=None, kd=100, first_frame=0, chunk=512):
+        """packed: the gather's wire format -- a flat float32 array of ``nrec`` count-prefixed records laid end to end, or the
+        ``(flat, nrec)`` pair ``gather_records(unpack=False)`` returns -> list of CSV lines.  Walked in chunks of records so the
+        line buffer can be sized from the ids issued so far (a line has a cell group for every id up to the frame's largest)."""
+        if isinstance(packed, tuple):
+            packed, nrec = packed
+        packed = np.ascontiguousarray(packed, np.float32).reshape(-1)
+        nrec = int(nrec)
+        lines, o, done = [], 0, 0
+        while done < nrec:
+            k, e, dets = 0, o, 0
+            while k < chunk and done + k < nrec:
+                if e >= packed.size:
+                    raise RuntimeError("wire format: %d records announced, data ends in record %d" % (nrec, done + k))
+                n = int(packed[e])
+                e += 1 + 13 * n + 2 * n * n + n * self.edim
+                if n < 0 or n > kd or e > packed.size:
+                    raise RuntimeError("wire format: record %d announces %d detections, %d floats past the end" % (done + k, n, e - packed.size))
+                dets += n
+                k += 1
+            cap = (1 << 12) + k * (16 + 4 * (self.max_id + dets)) + 40 * dets
+            buf = self._C.create_string_buffer(cap)
+            w = self._lib.apse_replay_packed(self._h, packed[o:].ctypes.data, int(e - o), k, int(kd), int(first_frame + done), buf, cap)
+            if w < 0:
+                raise RuntimeError("apse_replay_packed failed (%d)" % w)
+            lines += buf.raw[:w].decode().split("\n")[:-1]
+            o, done = e, done + k
+        return lines

@@ -197,6 +197,12 @@ class TrackPredictor:
         sl = self._prefetched
         if sl is None or self.frame_preprocessor is not None:
             return
+        key = self.model._ctx_key
+        if key is None or tuple(sl.dev.shape[1:3]) != tuple(key[0]) or sl.dev.shape[0] > int(self.cfg.APSE.MAX_BATCH):
+            # an announced frame of ANOTHER size: staging it would rebuild the context while this frame's results copy is still
+            # pending (read_begin .. read_end).  Leave the slot to the next call's normal upload path (it still finds the frame
+            # resident); no pre-stage, hence no run-ahead.
+            return
         self._prefetched = None
         torch.cuda.current_stream(self.model.device).wait_event(sl.h2d_done)
         self.model.preprocess_frames(sl.dev, tag=sl.key)

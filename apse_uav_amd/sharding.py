@@ -12,6 +12,7 @@ import torch
 
 _FIELDS = (("boxes", np.float32, 4), ("scores", np.float32, 1), ("classes", np.int64, 1), ("centroids", np.int32, 2),
            ("mass", np.int32, 1), ("rects", np.int32, 4))
+_ROW = sum(w for _, _, w in _FIELDS)          # 13 floats per detection in front of the closest-point table and the embedding
 
 
 def shard_frames(n_frames, rank, world):
@@ -21,77 +22,87 @@ def shard_frames(n_frames, rank, world):
     return lo, min(lo + per, n_frames)
 
 
-def pack_record(rec, kd, edim):
-    """Record -> flat f32 vector of fixed length (so one tensor gather moves every frame)."""
+def record_len(n, edim=128):
+    """Floats of the compact record of a frame with ``n`` detections: count, n x 13 fields, n x n x 2 closest points,
+    n x edim embeddings -- 597 floats (2.4 KB) at n = 4, 1257 (5 KB) at n = 8, 34 101 (136 KB) at the n = 100 cap."""
+    return 1 + n * _ROW + n * n * 2 + n * edim
+
+
+def pack_record(rec, kd=100, edim=128):
+    """Record -> count-prefixed flat f32 vector (the wire format of the gather; SURVEY 8e: "fixed-size record per frame" is
+    relaxed to a count-prefixed one so a frame costs what it holds).  Every integer field is < 2^24: exact in f32."""
     n = len(rec["scores"])
-    out = np.zeros(record_len(kd, edim), np.float32)
+    if n > kd:
+        raise ValueError("record with %d detections, cap %d" % (n, kd))
+    out = np.empty(record_len(n, edim), np.float32)
     out[0] = n
     o = 1
     for name, _, width in _FIELDS:
-        a = np.asarray(rec[name]).reshape(n, width).astype(np.float32)    # all values < 2^24: exact in f32
-        out[o:o + n * width] = a.reshape(-1)
-        o += kd * width
-    cl = np.asarray(rec["closest"], np.float32).reshape(n, n, 2)
-    blk = np.zeros((kd, kd, 2), np.float32)
-    blk[:n, :n] = cl
-    out[o:o + kd * kd * 2] = blk.reshape(-1)
-    o += kd * kd * 2
-    emb = np.zeros((kd, edim), np.float32)
-    emb[:n] = rec["embeddings"]
-    out[o:o + kd * edim] = emb.reshape(-1)
+        out[o:o + n * width] = np.asarray(rec[name]).reshape(n * width)
+        o += n * width
+    out[o:o + n * n * 2] = np.asarray(rec["closest"], np.float32).reshape(n * n * 2)
+    o += n * n * 2
+    out[o:o + n * edim] = np.asarray(rec["embeddings"], np.float32).reshape(n * edim)
     return out
 
 
-def record_len(kd, edim):
-    return 1 + kd * sum(w for _, _, w in _FIELDS) + kd * kd * 2 + kd * edim
-
-
-def unpack_record(vec, kd, edim):
+def unpack_record(vec, kd=100, edim=128):
+    """One compact record (a vector that starts with it) -> record dict; ``rec["wire_floats"]`` = floats consumed."""
     n = int(vec[0])
+    if n < 0 or n > kd or record_len(n, edim) > len(vec):
+        raise ValueError("corrupt record: count %d, %d floats left" % (n, len(vec)))
     rec = {}
     o = 1
     for name, dt, width in _FIELDS:
         a = vec[o:o + n * width].reshape(n, width).astype(dt)
         rec[name] = a[:, 0] if width == 1 else a
-        o += kd * width
-    rec["closest"] = vec[o:o + kd * kd * 2].reshape(kd, kd, 2)[:n, :n].astype(np.int32)
-    o += kd * kd * 2
-    rec["embeddings"] = vec[o:o + kd * edim].reshape(kd, edim)[:n].astype(np.float32).copy()
+        o += n * width
+    rec["closest"] = vec[o:o + n * n * 2].reshape(n, n, 2).astype(np.int32)
+    o += n * n * 2
+    rec["embeddings"] = vec[o:o + n * edim].reshape(n, edim).astype(np.float32).copy()
     rec["packed_index"] = np.arange(n)
+    rec["wire_floats"] = o + n * edim
     return rec
 
 
-def gather_records(records, rank, world, device, kd=100, edim=128, unpack=True):
-    """All ranks call this once; rank 0 gets the records of every rank in rank order (frame order for
-    contiguous shards), the others get None.  Ranks may hold different numbers of frames.
+def unpack_stream(flat, nrec, kd=100, edim=128):
+    """``nrec`` compact records laid end to end -> list of record dicts."""
+    out, o = [], 0
+    for _ in range(nrec):
+        r = unpack_record(flat[o:], kd, edim)
+        o += r.pop("wire_floats")
+        out.append(r)
+    return out
 
-    One collective on the data path: ``all_gather_into_tensor`` of the padded record block (RCCL over xGMI
-    with the "nccl" backend, gloo on CPU).  The payload is KBs..MBs per rank, so gathering to every rank
-    instead of only rank 0 costs nothing measurable and uses the best-supported RCCL primitive."""
+
+def gather_records(records, rank, world, device, kd=100, edim=128, unpack=True):
+    """All ranks call this once; rank 0 gets the records of every rank in rank order (frame order for contiguous shards),
+    the others get None.  Ranks may hold different numbers of frames and frames different numbers of detections.
+
+    The exchange step of the path (visualize_uav.py:186-233 run frame-sharded): each rank lays its compact records end to
+    end; a 16-byte all-gather tells every rank the (frames, floats) of the others, then ONE ``dist.gather`` moves the
+    payloads to rank 0 only (RCCL over xGMI with the "nccl" backend, gloo on CPU) -- a 2 734-frame run on 8 GPUs at N = 8
+    moves 1.7 MB per rank instead of the 47 MB per rank to every rank that worst-case records cost.
+    ``unpack=False``: (flat f32 array, number of records) for ``NativeReplay.run_packed``."""
     import torch.distributed as dist
-    L = record_len(kd, edim)
-    cnt = torch.tensor([len(records)], device=device, dtype=torch.int64)
-    cnts = torch.zeros((world,), device=device, dtype=torch.int64)
-    dist.all_gather_into_tensor(cnts, cnt)
-    counts = [int(v) for v in cnts.cpu().tolist()]
-    mx = max(max(counts), 1)
-    buf = torch.zeros((mx, L), dtype=torch.float32)
-    for i, r in enumerate(records):
-        buf[i] = torch.from_numpy(pack_record(r, kd, edim))
+    flat = np.concatenate([pack_record(r, kd, edim) for r in records]) if records else np.zeros((0,), np.float32)
+    mine = torch.tensor([len(records), flat.size], device=device, dtype=torch.int64)
+    sizes = torch.zeros((world * 2,), device=device, dtype=torch.int64)
+    dist.all_gather_into_tensor(sizes, mine)
+    sizes = sizes.cpu().view(world, 2).tolist()
+    mx = max(max(int(s[1]) for s in sizes), 1)
+    buf = torch.zeros((mx,), dtype=torch.float32)
+    buf[:flat.size] = torch.from_numpy(flat)
     buf = buf.to(device)
-    out = torch.empty((world * mx, L), dtype=torch.float32, device=device)
-    dist.all_gather_into_tensor(out, buf)
+    parts = [torch.empty((mx,), dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, parts, dst=0)
     if rank != 0:
         return None
-    h = out.cpu().numpy().reshape(world, mx, L)
+    h = np.concatenate([parts[r].cpu().numpy()[:int(sizes[r][1])] for r in range(world)]) if world else flat
+    nrec = sum(int(s[0]) for s in sizes)
     if not unpack:
-        # wire format kept: rank-ordered [frames, L] array for NativeReplay.run_packed
-        return np.concatenate([h[r, :counts[r]] for r in range(world)], axis=0)
-    res = []
-    for r in range(world):
-        for i in range(counts[r]):
-            res.append(unpack_record(h[r, i], kd, edim))
-    return res
+        return h, nrec
+    return unpack_stream(h, nrec, kd, edim)
 
 
 def spawn_local_ranks(script, argv, n, extra_env=None):

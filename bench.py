@@ -326,7 +326,7 @@ def main():
     if dist is not None:
         packed = gather_records(records, rank, world, coll_dev, unpack=False)   # the single exchange step (RCCL over xGMI)
         if rank == 0:
-            replay.run_packed(packed, kd=100)                              # sequential id assignment + CSV lines (C++)
+            replay.run_packed(packed, kd=100)                              # (flat, nrec): sequential id assignment + CSV lines (C++)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

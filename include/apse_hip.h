@@ -54,8 +54,9 @@ typedef struct apse_config {
     float assoc_scale;            /* roi_pool spatial scale = p2 width / frame width (rcnn_tracker.py:165) */
     int compute_dtype;            /* 0 = exact f32 MFMA everywhere (reference numerics); 1 = bf16, 2 = f16 matrix cores with
                                      f32 accumulate for the trunk / head GEMMs (decision layers stay f32) */
-    int storage16;                /* with compute_dtype 1/2: 1 = activations live in HBM in the 16-bit operand type (half
-                                     the traffic, no conversion on the way to the matrix cores); 0 = f32 storage */
+    int storage16;                /* with compute_dtype 1/2: must be 1 = activations live in HBM in the 16-bit operand type (half
+                                     the traffic, no conversion on the way to the matrix cores).  The f32-storage variant of
+                                     the 16-bit modes was removed in round 4 (apse_create refuses it); ignored for f32 */
 } apse_config;
 
 /* Byte offsets of the per-forward results block (one D2H copy, apse_read_results). n = max_batch*dets_per_image. */
@@ -122,11 +123,13 @@ int apse_rpn_levels(apse_ctx* ctx, int batch, int level_mask, void* stream);
 /* Box branch + FastRCNNOutputs.inference (track_rcnn.py:51) -> packed detection list. */
 int apse_box_head(apse_ctx* ctx, int batch, void* stream);
 /* roi_heads.forward_with_given_boxes (track_rcnn.py:52-54): host arrays, boxes in resized-image pixels,
- * counts[batch] detections per image, concatenated.  Replaces apse_rpn + apse_box_head. */
+ * counts[batch] detections per image, concatenated.  Replaces apse_rpn + apse_box_head.  Enqueues only: the arrays are
+ * copied into pinned staging owned by the context before the call returns and may be freed by the caller at once. */
 int apse_set_detections(apse_ctx* ctx, const float* boxes_host, const int* classes_host, const float* scores_host,
                         const int* counts_host, int batch, void* stream);
 /* Mask branch + detector_postprocess/paste + centroids + closest-point table
- * (track_rcnn.py:51,57; mask_utils.py:6-38). */
+ * (track_rcnn.py:51,57; mask_utils.py:6-38).  Idempotent on one detection list: a repeated call (a timing loop) gives the
+ * same masses / centroids, not doubled ones. */
 int apse_mask_tail(apse_ctx* ctx, int batch, void* stream);
 /* roi_pool(p2) + AssociationHead (rcnn_tracker.py:156-189, association_head.py:16-27). */
 int apse_embed(apse_ctx* ctx, int batch, void* stream);
@@ -170,7 +173,8 @@ double apse_flops(apse_ctx* ctx, int batch, double proposals, double detections)
  * 0..3 = 128x128, 64x64, 128x32, 128x64 implicit-GEMM tiles, 4..7 their 32-deep / 8-wave variants, 8 = 256x128,
  * 9 / 10 = the memory-streaming 1x1 kernels, A strip resident / streamed, 11 = the LDS-DMA
  * 256x128 kernel of the 16-bit modes, 12 = the fused stem + max-pool kernel of the 16-bit modes, 13 = the <= 16-channel
- * head kernel (a split-K launch includes its reduce pass). */
+ * head kernel (a split-K launch includes its reduce pass).  With the two-half read a forward enqueued between
+ * apse_read_results_begin and _end keeps its own event pairs: _end accounts exactly the forward whose results it returns. */
 int apse_profile(apse_ctx* ctx, int enable);
 int apse_profile_read(apse_ctx* ctx, double* out42, int reset);
 
@@ -184,7 +188,8 @@ typedef struct apse_conv_desc {
                                ones), 4/5 = 64x64 / 128x32 with 32-deep steps, 6/7 = 64x64 with 8 waves in two k groups, 8 = 256x128
                                (16-bit operands stored 16-bit only; otherwise 128x128) */
     int splitk;             /* 0 auto */
-    int prec;               /* 0 f32 MFMA; 1 bf16 / 2 f16 MFMA (operands rounded at LDS staging, f32 accumulate) */
+    int prec;               /* 0 f32 MFMA; 1 bf16 / 2 f16 MFMA with f32 accumulate: x must be STORED in that type (x_st == prec),
+                               filter rows whole 64-element steps, no fuse_reduce -- anything else is refused */
     int fuse_reduce;        /* split-K: 1 = last-arriving block reduces in the launch, 0 = separate reduce kernel */
     int x_st, res_st, y_st; /* storage type of x / residual / y: 0 f32, 1 bf16, 2 f16 (16-bit tensors need C % 8 == 0;
                                with prec 1/2 a 16-bit x must be stored in the operand type) */
@@ -241,9 +246,10 @@ apse_replay* apse_replay_create(int host_id, int embed_dim, float dist_thresh, i
 void apse_replay_destroy(apse_replay* r);
 int apse_replay_step(apse_replay* r, int frame_idx, int n, const float* emb_host, const int* centroid_host,
                      const int* closest_host, char* line_out, int line_cap, int* det_ids_out);
-/* nrec records in the wire format of the sharded gather (apse_uav_amd/sharding.py::pack_record): one call for a
- * whole rank's shard; lines separated by '\n'; returns bytes written. */
-long long apse_replay_packed(apse_replay* r, const float* records_host, int nrec, int stride_floats, int dets_per_image,
+/* nrec records laid end to end in the wire format of the sharded gather (apse_uav_amd/sharding.py::pack_record: count-prefixed,
+ * `total_floats` in all; a frame with n detections is 1 + 13 n + 2 n^2 + n * embed_dim floats): one call for a whole run;
+ * lines separated by '\n'; returns bytes written. */
+long long apse_replay_packed(apse_replay* r, const float* records_host, long long total_floats, int nrec, int dets_per_image,
                              int first_frame, char* lines_out, long long cap);
 int apse_replay_max_id(const apse_replay* r);
 int apse_replay_next_id(const apse_replay* r);

@@ -48,6 +48,21 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, logdir):
     assert two_raw == one_raw
 
 
+def test_config3_two_ranks_bf16_batch4_preproc_given_boxes(tmp_path, logdir):
+    """BASELINE configs[3] as SURVEY 8d restates it (dynamic sequence, batch 4, bf16 storage / f32 accumulate, fused undistort +
+    gamma, frame-sharded, gather -> single ordered CSV identical to the config-2 CSV), in the deterministic given-boxes form
+    (track_rcnn.py:52-54): 18 frames as 10 + 8 on two ranks -- ragged last batches on both -- against the one-rank run."""
+    common = ["--frames", "18", "--kind", "dynamic", "--size", "2160x3840", "--dtype", "bf16", "--batch", "4", "--preproc", "--given-boxes"]
+    one, one_raw = _run(common, tmp_path, "c3_one")
+    two, two_raw = _run(common + ["--gpus", "2"], tmp_path, "c3_two", {"APSE_DIST_BACKEND": "gloo"})
+    rows = one.split("\n")
+    with open(os.path.join(logdir, "multirank.log"), "a") as f:
+        f.write("configs[3] given-boxes bf16 batch 4 preproc: two-rank csv equal: %s, raw equal: %s\n%s\n" % (one == two, one_raw == two_raw, one[:500]))
+    assert len(rows) == 2 + 18 + 1
+    assert all(sum(1 for c in r.split(",")[1:] if c) >= 8 for r in rows[2:-1])      # >= 2 vehicles with centroid + closest point per row
+    assert two == one and two_raw == one_raw
+
+
 def test_start_frame_rows_equal_full_run(tmp_path, logdir):
     """--start-frame 3 on a 9-frame sequence.  Static sequence (zero motion: every frame holds the same vehicles, so the
     tracker that starts at frame 3 issues the same ids in the same order): its rows must be rows 3.. of the full run,

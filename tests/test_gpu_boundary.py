@@ -149,6 +149,67 @@ def test_forward_equals_the_five_stage_calls(ctx):
     assert b"batch" in lib.apse_last_error(model._ctx)
 
 
+def test_mask_tail_twice_gives_the_same_record(ctx):
+    """paste_masks adds into integer sums that only pack_detections used to clear; a staged-API caller repeating
+    apse_mask_tail on one detection list (a timing loop) must not get doubled masses / moved centroids."""
+    from apse_uav_amd import _lib
+    from hip_helpers import _live_bytes
+    lib = _lib.load()
+    model = ctx["pr"].model
+    dev = ctx["pr"]._upload([ctx["frame"]])
+    s = _lib.stream_ptr()
+    model.preprocess_frames(dev)
+    for fn in ("apse_backbone", "apse_rpn", "apse_box_head", "apse_mask_tail", "apse_embed"):
+        _lib.check(getattr(lib, fn)(model._ctx, 1, s), model._ctx, fn)
+    n1, once = _live_bytes(model, model.read(1))
+    mass1 = model.last_results.mass[:n1].copy()
+    for _ in range(2):
+        _lib.check(lib.apse_mask_tail(model._ctx, 1, s), model._ctx, "apse_mask_tail")
+    _lib.check(lib.apse_embed(model._ctx, 1, s), model._ctx, "apse_embed")
+    n2, again = _live_bytes(model, model.read(1))
+    assert n1 == n2 > 0 and int(mass1.sum()) > 0
+    assert np.array_equal(model.last_results.mass[:n2], mass1) and once == again
+
+
+def test_profile_with_a_forward_between_the_read_halves(ctx):
+    """apse_profile(1) together with the two-half read and a forward enqueued between _begin and _end (TrackPredictor
+    run-ahead).  The event pool has two halves, so _end accounts exactly the forward it returns: the launch counts of two such
+    steps are twice those of one plain profiled step."""
+    from apse_uav_amd import _lib
+    lib = _lib.load()
+    model = ctx["pr"].model
+    dev = ctx["pr"]._upload([ctx["frame"]])
+    NCFG = 14
+
+    def read_prof():
+        pr = (C.c_double * (3 * NCFG))()
+        lib.apse_profile_read(model._ctx, C.byref(pr), 1)
+        return np.array(list(pr)).reshape(NCFG, 3)
+
+    model.preprocess_frames(dev)
+    model.run(1)
+    model.read(1)                                      # context built, nothing pending
+    lib.apse_profile(model._ctx, 1)
+    model.preprocess_frames(dev)
+    model.run(1)
+    model.read(1)
+    one = read_prof()
+    model.preprocess_frames(dev)
+    model.run(1)
+    for k in range(2):
+        model.read_begin(1)
+        if k == 0:
+            model.preprocess_frames(dev)
+            model.run(1)                               # the next forward, enqueued between the two halves of this read
+        model.read_end(1)
+    two = read_prof()
+    lib.apse_profile(model._ctx, 0)
+    assert one[:, 2].sum() > 10
+    assert np.array_equal(two[:, 2], 2 * one[:, 2])    # every launch of both forwards timed once, none dropped
+    assert np.allclose(two[:, 1], 2 * one[:, 1])       # and attributed the right FLOPs
+    assert (two[:, 0][one[:, 2] > 0] > 0).all()
+
+
 def test_selective_scan_contract(ctx, logdir):
     """SelectiveMaskRCNN.scan: the reference's model-level entry of the Selective* predictor: proposals from the last
     pyramid level only; returns the post-processed list alone (no feature dict)."""

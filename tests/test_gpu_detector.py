@@ -180,7 +180,7 @@ def test_pipelined_tracker_equals_sequential(setup, logdir, depth, want_masks):
     _log(logdir, "pipelined/depth%d" % depth, dict(frames=len(frames), ids_last=ref[-1][0]))
 
 
-@pytest.mark.parametrize("storage", [True, False], ids=["store16", "store32"])
+@pytest.mark.parametrize("storage", [True], ids=["store16"])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_bf16_mode_vs_bf16_oracle(setup, logdir, dtype, storage):
     """cfg.APSE.DTYPE = "bf16": bf16 matrix cores, f32 accumulate / storage.  Checked against the oracle run

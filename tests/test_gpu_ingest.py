@@ -183,3 +183,26 @@ def test_announced_loop_over_a_longer_dynamic_run(env):
         p = _step(a, fr[t], t)
         g = _step(b, fr[t], t, upcoming=fr[t + 1] if t + 1 < 24 else None)
         assert g == p, "frame %d differs" % t
+
+
+def test_announced_frame_of_another_size(env, plain):
+    """``upcoming=`` with a frame whose H x W differs from the current one.  Pre-staging it would rebuild the
+    context between read_begin and read_end and lose the current frame's results; the predictor must skip the pre-stage (and the
+    run-ahead) and let the next call take the normal upload path.  Frame 0 (4K) announcing a 1080p frame, then that frame, then
+    4K again: the 4K records equal the plain loop's."""
+    from apse_uav_amd.synthetic import SyntheticSequence
+    tr = _tracker(env)
+    fr = env["frames"]
+    small = SyntheticSequence("dynamic", 1080, 1920).frame(3)
+    a = _step(tr, fr[0], 0, upcoming=small)
+    assert a[2] == plain[0][2] and a[3] == plain[0][3]
+    assert tr.predictor.model._running_tag is None and tr.predictor.model._input_tag is None     # nothing staged, nothing run ahead
+    pred, _ = tr.predictor(small)                       # the announced frame: resident (prefetched), context rebuilt for 1080p here
+    assert pred["instances"].image_size == (1080, 1920)
+    tr2 = _tracker(env)
+    ref_small, _ = tr2.predictor(small)
+    assert torch.equal(pred["instances"].pred_boxes.tensor, ref_small["instances"].pred_boxes.tensor)
+    b, _ = tr.predictor(fr[1])                          # back to 4K
+    from apse_uav_amd.sharding import pack_record
+    ref = _tracker(env).predictor(fr[1])[0]["instances"]
+    assert pack_record(b["instances"]._record).tobytes() == pack_record(ref._record).tobytes()

@@ -87,39 +87,7 @@ def test_conv2d_parity(case, logdir):
     assert st["rel_to_max"] < 2e-5, st          # f32 tolerance: accumulation-order noise only
 
 
-@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "f16"])
-@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv2d_bf16_parity(case, prec, logdir):
-    """bf16 matrix-core variant: operands rounded to bf16 at staging, f32 accumulate/storage.  Reference =
-    torch CPU f32 convolution of the bf16-rounded operands (same quantisation points)."""
-    from hip_helpers import hip_conv2d, err_stats
-    import zlib
-    name, B, Cin, H, W, Cout, K, stride, pad, relu, res_mode, cfg, splitk = case
-    if cfg == 11:
-        pytest.skip("conv_glds16 takes 16-bit stored operands only (test_conv2d_16bit_storage)")
-    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
-    x = torch.randn(B, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
-    b = torch.randn(Cout, generator=g)
-    r16 = lambda t: t.to(torch.bfloat16 if prec == 1 else torch.float16).to(torch.float32)
-    ref = F.conv2d(r16(x), r16(w), b, stride=stride, padding=pad)
-    res = None
-    if res_mode == 1:
-        res = torch.randn(ref.shape, generator=g)
-        ref = ref + res
-    elif res_mode == 2:
-        res = torch.randn(B, Cout, ref.shape[2] // 2, ref.shape[3] // 2, generator=g)
-        ref = ref + F.interpolate(res, scale_factor=2, mode="nearest")
-    if relu:
-        ref = F.relu(ref)
-    out = hip_conv2d(x, w, b, stride, pad, relu, res, res_mode, cfg, splitk, prec=prec)
-    st = err_stats(out, ref)
-    _log(logdir, "conv_16bit/%d/" % prec + name, st)
-    assert st["nan"] == 0
-    assert st["rel_to_max"] < 2e-5, st          # products of bf16 values are exact in f32: order-of-sum noise only
-
-
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0])
 @pytest.mark.parametrize("shape", [(1, 512, 12, 14, 128, 3, 5, 1), (1, 256, 48, 84, 256, 3, 8, 0), (3, 256, 10, 10, 128, 10, 64, 1),
                                    (1, 1024, 24, 42, 512, 1, 4, 1)])
 def test_conv2d_fused_splitk(shape, prec, logdir):
@@ -244,7 +212,7 @@ def test_conv1x1_stream(case, prec, logdir):
         same = float((out == tiled).float().mean())
         _log(logdir, "conv_stream/%d/" % prec + name, dict(max=float(diff.max()), frac_differs=frac, equal_to_tiled_frac=same))
         assert bool((diff <= tol).all()) and frac < 0.02
-        assert same > 0.98                      # same chain up to the order of the bias / residual adds
+        assert same == 1.0                      # [1.0 in every logged case, rounds 2-3] same MFMA chain, bias / residual added at the same points: bit-identical
 
 
 SKINNY_CASES = [
@@ -640,6 +608,12 @@ def test_c_abi_rejects_bad_arguments():
     assert lib.apse_conv2d(C.byref(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(y), _lib.ptr(y), None, 0, s) < 0
     d.res_mode, d.Cout, d.prec, d.x_st = 0, 16, 1, 2                                             # f16 storage with bf16 operands
     assert lib.apse_conv2d(C.byref(d), _lib.ptr(x), _lib.ptr(w), None, None, _lib.ptr(y), None, 0, s) < 0
+    d.x_st, d.Cin, d.Cout = 0, 64, 128                                                           # 16-bit operands from f32-STORED activations: the
+    x3 = torch.zeros(1, 8, 8, 64, device="cuda")                                                 # converting kernel was removed in round 4 -> refused
+    w3 = torch.zeros(128 * 64, device="cuda")
+    y3 = torch.zeros(1, 8, 8, 128, device="cuda")
+    assert lib.apse_conv2d(C.byref(d), _lib.ptr(x3), _lib.ptr(w3), None, None, _lib.ptr(y3), None, 0, s) < 0
+    d.prec = 0
     assert lib.apse_conv2d(None, _lib.ptr(x), _lib.ptr(w), None, None, _lib.ptr(y), None, 0, s) < 0
     # context-level calls on a null / unfinished context
     assert lib.apse_backbone(None, 1, s) < 0
@@ -649,4 +623,9 @@ def test_c_abi_rejects_bad_arguments():
     ctx = C.c_void_p()
     assert lib.apse_create(C.byref(cfg), C.byref(ctx)) < 0 and not ctx.value
     assert b"size" in lib.apse_last_error(None)
+    cfg.struct_size = C.sizeof(_lib.Config)
+    cfg.max_batch, cfg.frame_w, cfg.frame_h, cfg.num_classes, cfg.dets_per_image = 1, 480, 270, 4, 100
+    cfg.compute_dtype, cfg.storage16 = 1, 0                                                      # 16-bit matrix cores on f32-stored tensors: removed
+    assert lib.apse_create(C.byref(cfg), C.byref(ctx)) < 0 and not ctx.value
+    assert b"storage16" in lib.apse_last_error(None)
     torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 """-m gpu: the collective path of a frame-sharded run on the RCCL backend ("nccl" on ROCm), as far as one GPU can take it:
 a one-rank process group on cuda:0 running exactly the calls of bench.py / tools/run_sequence.py -- the record gather
-(``sharding.gather_records``: two ``all_gather_into_tensor`` on device tensors), the barrier and the max-over-ranks reduction of
+(``sharding.gather_records``: a 16-byte ``all_gather_into_tensor`` of sizes + one ``dist.gather`` of the compact payloads, on device tensors), the barrier and the max-over-ranks reduction of
 the elapsed time (float64).  More ranks need more GPUs (RCCL refuses two ranks on one device); the multi-rank logic itself is
 covered on gloo (tests/test_sharding_gloo.py).  Reference loop being sharded: /root/reference/dcnn/scripts/tests/visualize_uav.py:186-221."""
 import socket
@@ -32,8 +32,8 @@ def test_record_gather_and_timing_reduction_on_rccl():
                              mass=rng.integers(1, 5000, n).astype(np.int32), rects=rng.integers(0, 2000, (n, 4)).astype(np.int32),
                              closest=rng.integers(0, 2000, (n, n, 2)).astype(np.int32), embeddings=rng.random((n, 128), dtype=np.float32)))
         dist.barrier()
-        packed = gather_records(recs, 0, 1, dev, unpack=False)
-        assert packed.shape == (3, record_len(100, 128))
+        packed, nrec = gather_records(recs, 0, 1, dev, unpack=False)
+        assert nrec == 3 and packed.shape == (record_len(3) + record_len(0) + record_len(8),)
         got = gather_records(recs, 0, 1, dev)
         assert len(got) == 3
         for a, b in zip(recs, got):

@@ -2,6 +2,7 @@
 RcnnTracker.next_record + log_line path line for line, including births, deaths after 100 unseen frames,
 absent host, empty frames and empty masks."""
 import numpy as np
+import pytest
 import torch
 
 
@@ -65,8 +66,11 @@ def test_native_replay_packed_wire_format():
     from apse_uav_amd.engines.replay import FastReplay, NativeReplay
     from apse_uav_amd.sharding import pack_record
     recs = _stream(120, seed=5)
-    packed = np.stack([pack_record(r, 100, 128) for r in recs])
+    packed = np.concatenate([pack_record(r, 100, 128) for r in recs])
     fr, nr = FastReplay(2), NativeReplay(2)
     ref = [fr.step(r, 7 + t)[0] for t, r in enumerate(recs)]
-    got = nr.run_packed(packed, kd=100, first_frame=7)
+    got = nr.run_packed(packed, len(recs), kd=100, first_frame=7, chunk=50)       # 120 records: three chunks, ids carried across them
     assert got == ref and nr.max_id == fr.max_id
+    assert NativeReplay(2).run_packed((packed, len(recs)), first_frame=7) == ref
+    with pytest.raises(RuntimeError):
+        NativeReplay(2).run_packed(packed[:-5], len(recs))                        # truncated payload: refused, not read past

@@ -63,8 +63,11 @@ def test_pack_unpack_roundtrip_and_shards():
     from apse_uav_amd.sharding import pack_record, record_len, shard_frames, unpack_record
     r = _records(3, 4)[0]
     v = pack_record(r, 100, 128)
-    assert v.shape == (record_len(100, 128),)
+    n = len(r["scores"])
+    assert v.shape == (record_len(n, 128),) == (1 + 13 * n + 2 * n * n + 128 * n,)      # count-prefixed: a frame costs what it holds
+    assert record_len(4) * 4 < 2500 and record_len(100) == 34101                       # ~2.3 KB typical, 136 KB worst case
     u = unpack_record(v, 100, 128)
+    assert u.pop("wire_floats") == v.size
     for k in ("boxes", "scores", "classes", "centroids", "mass", "rects", "closest", "embeddings"):
         assert np.array_equal(u[k], r[k]), k
     cover = []
