@@ -88,6 +88,8 @@ def load():
         "apse_read_results_begin": ([vp, vp, sz, vp], i),
         "apse_read_results_end": ([vp, vp], i),
         "apse_copy_mask_window": ([vp, i, i, i, i, i, vp, vp], i),
+        "apse_copy_mask_windows": ([vp, i, vp, vp, vp, vp, vp], i),
+        "apse_host_copy": ([vp, vp, sz, i], i),
         "apse_feature_shape": ([vp, C.c_char_p, C.POINTER(C.c_int * 3)], i),
         "apse_export_feature": ([vp, C.c_char_p, vp, i, vp], i),
         "apse_debug_tensor": ([vp, C.c_char_p, vp, sz, C.POINTER(sz), vp], i),
@@ -129,7 +131,7 @@ def load():
 EXPORTS = ["apse_create", "apse_destroy", "apse_last_error", "apse_version", "apse_set_weight", "apse_finalize_weights",
            "apse_set_resize_tables", "apse_set_camera", "apse_preprocess_frames", "apse_preprocess_images", "apse_backbone", "apse_rpn", "apse_rpn_levels",
            "apse_box_head", "apse_set_detections", "apse_mask_tail", "apse_embed", "apse_forward", "apse_results_describe",
-           "apse_read_results", "apse_read_results_begin", "apse_read_results_end", "apse_copy_mask_window", "apse_feature_shape", "apse_export_feature", "apse_debug_tensor",
+           "apse_read_results", "apse_read_results_begin", "apse_read_results_end", "apse_copy_mask_window", "apse_copy_mask_windows", "apse_host_copy", "apse_feature_shape", "apse_export_feature", "apse_debug_tensor",
            "apse_flops", "apse_profile", "apse_profile_read", "apse_conv_packed_elems", "apse_conv_pack_weight", "apse_conv2d", "apse_maxpool3x3s2",
            "apse_maxpool3x3s2_typed", "apse_roi_align", "apse_roi_align_typed", "apse_roi_pool", "apse_roi_features", "apse_nms_rank", "apse_mask_centroid_dense", "apse_mask_closest_dense",
            "apse_l2_normalize", "apse_sqdist", "apse_undistort_gamma", "apse_lab_tables_host", "apse_resize_normalize", "apse_replay_create", "apse_replay_destroy",

@@ -63,6 +63,7 @@ int apse_conv_pick_cfg(int M, int Cout, int steps, int* splitk);
 bool apse_conv1x1_stream_ok(const ConvParams& p);
 int apse_launch_conv1x1_stream(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 bool apse_conv_glds16_ok(const ConvParams& p);
+bool apse_conv_glds16_small(const ConvParams& p);   // the 128x128 tile of that kernel would be picked (few 256-row tiles)
 bool apse_conv_skinny_ok(const ConvParams& p);
 int apse_launch_conv_skinny(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int apse_launch_conv_glds16(const ConvParams& p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);

@@ -22,24 +22,45 @@ typedef _Float16 g16_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 g16_mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 g16_mfma(g16_f16x8 a, g16_f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-#define GL_BM 256
+#ifndef GL_PP
+#define GL_PP 1          // 1: ping-pong schedule of the two wave groups (round 4, below); 0: the round-2 loop (A/B builds)
+#endif
 #ifndef GL_ABLATE
 #define GL_ABLATE 0      // diagnostics only (tools/gpu_glds_ablate.sh): 1 no MFMA, 2 DMAs of the first two stages only, 3 no fragment reads, 4 two of three A fetches out of range
 #endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// BN = 128: 8 waves as 4 x 2, 64 x 64 per wave, three stages of 48 KB.  BN = 256: 8 waves as 2 x 4, 128 x 64 per wave, two stages
-// of 64 KB -- per matrix-pipe cycle a third fewer bytes through L2 -> LDS (32 instead of 47 B/clk/CU, of ~64 the port gives) and a
-// quarter fewer fragment bytes out of LDS; the C tile (256 x 256 f32 does not fit) leaves in two halves of 128 columns.
-template <int PR, int GL_BN>
+// BM x BN = 256 x 128: 8 waves as 4 x 2, 64 x 64 per wave, three stages of 48 KB.  256 x 256: 8 waves as 2 x 4, 128 x 64 per wave,
+// two stages of 64 KB -- per matrix-pipe cycle a third fewer bytes through L2 -> LDS (32 instead of 47 B/clk/CU, of ~64 the port
+// gives) and a quarter fewer fragment bytes out of LDS; the C tile (256 x 256 f32 does not fit) leaves in two halves of 128
+// columns.  128 x 128 (round 4): 8 waves as 4 x 2, 32 x 64 per wave, three stages of 32 KB -- for the layers whose M gives about
+// one 128 x 128 tile per CU but only half a wave of 256-row tiles (res4 at batch 4: M = 16 128, N = 256 -> 252 tiles).
+//
+// Ping-pong schedule (GL_PP, round 4).  The round-2 loop let all eight waves do the same thing at the same time: after each
+// stage's barrier every wave first issued fragment reads (matrix pipe idle), then every wave issued MFMAs (LDS idle); the SQ
+// counters showed the pipe busy 27-43 % with both the LDS side and the MFMA side about a stage long.  Now the waves form two
+// groups -- waves 0..3 and 4..7, one of each per SIMD -- that alternate in opposite phase: a stage is cut into NB blocks of CPB
+// k-chunks; a wave READS all fragments of a block (ds_read_b128 only), passes a barrier, then issues the block's MFMAs back to
+// back (s_setprio 1, the LDS-DMA pieces of a later stage riding in the gaps), passes a barrier, and so on; group 1 runs exactly one
+// slot behind group 0, so in every slot one wave of each SIMD is in its MFMA block while the other reads.  Slots (every boundary is
+// one workgroup barrier): group 0 READ(u) in slot 2u, MFMA(u) in 2u + 1; group 1 READ(u) in 2u + 1, MFMA(u) in 2u + 2.
+//   * WAR: stage X lands in the buffer of stage X - NS, last read by group 1 in slot 2 NB (X - AHEAD) - 1 (NS = AHEAD + 1); group 0
+//     issues its pieces of stage t + AHEAD in the MFMA block of the FIRST block of stage t (slot 2 NB t + 1), group 1 its pieces of
+//     stage t + 1 + AHEAD in the MFMA block of the LAST block of stage t (slot 2 NB (t + 1)) -- both behind that barrier;
+//   * RAW: stage X is first read by group 0 in slot 2 NB X.  In the slot before, group 0 is in the MFMA block and group 1 in the
+//     READ block of the last block of stage X - 1: each ends it with a counted s_waitcnt vmcnt that leaves only its own pieces of
+//     LATER stages outstanding ((AHEAD - 1) NPW), then the barrier: every wave's share of stage X is retired by its issuer before
+//     a barrier every reader passes (cdna_hip_programming.md "read a staged buffer one phase AFTER the wait that retires it").
+// Same MFMA instruction, same k order per accumulator as before: results are bit-identical to the round-2 loop (tests).
+template <int PR, int GL_BM, int GL_BN>
 __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
     typedef typename std::conditional<PR == 1, bf16x8, g16_f16x8>::type op8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int GL_STAGE = (GL_BM + GL_BN) * 128;   // bytes per stage: 64 elements (128 B) per tile row
     constexpr int GL_NS = GL_BN == 128 ? 3 : 2;
     constexpr int WNW = GL_BN / 64;                   // waves along N (64 columns each)
-    constexpr int TMW = (GL_BM / (8 / WNW)) / 32;     // 32-row MFMA tiles per wave along M: 2 (BN 128) or 4 (BN 256)
-    constexpr int APW = GL_BM / 64, BPW = GL_BN / 64; // DMA pieces (8-row groups) per wave and stage: A 4, B 2 or 4
+    constexpr int TMW = (GL_BM / (8 / WNW)) / 32;     // 32-row MFMA tiles per wave along M: 1 (128 x 128), 2 (256 x 128) or 4 (256 x 256)
+    constexpr int APW = GL_BM / 64, BPW = GL_BN / 64; // DMA pieces (8-row groups) per wave and stage: A 2 or 4, B 2 or 4
     constexpr int NPW = APW + BPW;
     constexpr int LDC = 128 + 4;
     float* Cs = reinterpret_cast<float*>(smem);                     // epilogue view [256][LDC] (aliases the ring)
@@ -67,10 +88,10 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
 
     // ---- this lane's DMA rows: A groups 4 wave .. 4 wave + 3, B groups 2 wave, 2 wave + 1 (a group = 8 rows x 128 B = one
     // wave instruction); LDS slot (row, lane & 7) receives chunk cs = (lane & 7) ^ swz(row)
-    int a_iy0[4], a_ix0[4], a_base[4], a_cs[4];
+    int a_iy0[APW], a_ix0[APW], a_base[APW], a_cs[APW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < APW; ++i) {
+        const int row = (wave * APW + i) * 8 + (lane >> 3);
         const int m = m0 + row;
         a_cs[i] = ((lane & 7) ^ ((row >> 1) & 7)) << 3;            // element offset of the chunk inside the 64-element step
         if (m < M) {
@@ -96,7 +117,7 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w16), 0,
                                                                     (int)((((unsigned)(tiles_n * GL_BN)) * (unsigned)w_row) << 1), 0x00020000);
     int ld_r = 0, ld_q = 0;
-    // One DMA "piece" = one wave instruction (8 rows x 128 B).  Pieces 0..3: this wave's A groups, 4..: its B groups.
+    // One DMA "piece" = one wave instruction (8 rows x 128 B).  Pieces 0..APW-1: this wave's A groups, APW..: its B groups.
     // piece 0 also computes the step's scalars and advances (filter row, step) -- pieces of a stage are issued in order.
     int cur_q0 = 0, cur_rowoff = 0, cur_r = 0;
     unsigned cur_woff = 0;
@@ -108,16 +129,16 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
             cur_woff = (unsigned)((ld_r * p.KWCp + cur_q0) << 1);
             if (++ld_q == steps_per_row) { ld_q = 0; ++ld_r; }
         }
-        if (j < 4) {
+        if (j < APW) {
             const int iy = a_iy0[j] + cur_r;
             const int px = a_ix0[j] + ((cur_q0 + a_cs[j]) >> p.cin_log2);
             const unsigned okm = (unsigned)-(int)(((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)p.W));
             unsigned off = (((unsigned)(a_base[j] + cur_rowoff + a_cs[j]) << 1) & okm) | (0xfffffff0u & ~okm);
             if (GL_ABLATE == 4 && ((cur_q0 >> 6) % 3) != 0) off = 0xfffffff0u;      // what if two of three A fetches were free (tap reuse)?
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(smem + buf * GL_STAGE + wave * 4096 + j * 1024), 16, (int)off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(smem + buf * GL_STAGE + wave * (APW * 1024) + j * 1024), 16, (int)off, 0, 0, 0);
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(smem + buf * GL_STAGE + GL_BM * 128 + wave * (BPW * 1024) + (j - 4) * 1024), 16,
-                                                     (int)(b_off[j - 4] + cur_woff), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(smem + buf * GL_STAGE + GL_BM * 128 + wave * (BPW * 1024) + (j - APW) * 1024), 16,
+                                                     (int)(b_off[j - APW] + cur_woff), 0, 0, 0);
         }
     };
     auto issue = [&](int buf) {
@@ -134,6 +155,83 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
     constexpr int AHEAD = GL_NS - 1;                  // stages in flight beyond the one being computed
+#if GL_PP
+    constexpr int CPB = GL_BM == 128 ? 4 : 2;         // k-chunks (16 deep) per block: 8 / 8 / 16 MFMAs per block and wave
+    constexpr int NB = 4 / CPB;                       // blocks per 64-deep stage
+    constexpr int NMF = CPB * TMW * 2;                // MFMAs of a block
+    static_assert(NB == 2 || AHEAD >= 2, "one block per stage needs two stages in flight (the wait follows the issue in one block)");
+    static_assert(NPW <= NMF, "a stage's DMA pieces ride in the gaps of ONE MFMA block");
+    const int grp = wave >> 2;                        // waves w and w + 4 share a SIMD: one of each group per SIMD
+    const int U = T * NB;
+    int issued = 0;                                   // stages this wave has issued its pieces of
+    // group 1 runs one stage further ahead (its issue point is the block BEFORE group 0's, see above)
+    for (; issued < T && issued < AHEAD + grp; ++issued) issue(issued % GL_NS);
+    // stage 0 complete for this wave, leaving its later prologue stages in flight; then the barrier that vouches for all waves
+    if (issued <= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");          // slot 0: group 0 reads block 0
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 af[CPB][TMW], bf[CPB][2];
+    // the wait that retires stage t + 1 for this wave (at the end of the last block of stage t: group 0 behind its MFMAs, group 1
+    // behind its reads).  By then the wave has issued stages up to `issued - 1`; those beyond t + 1 may stay in flight.
+    auto wait_next = [&](int t) {
+        const int later = issued - (t + 2);           // own stages issued beyond t + 1: 0 .. AHEAD - 1 (+ 0 for group 1: same count, see header)
+        if (later <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+    };
+    static_assert(AHEAD <= 2, "wait_next distinguishes 0 or 1 later stages");
+    for (int u = 0; u < U; ++u) {
+        const int t = u / NB, h = u - t * NB;
+        const char* As = smem + (t % GL_NS) * GL_STAGE;
+        const char* Bs = As + GL_BM * 128;
+        // ---------------- READ block: every fragment of CPB chunks
+#pragma unroll
+        for (int cc = 0; cc < CPB; ++cc) {
+            const int ls = 2 * (h * CPB + cc) + fh;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                const int row = (wm * TMW + i) * 32 + fr;
+                af[cc][i] = *reinterpret_cast<const f32x4*>(As + row * 128 + ((ls ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = (wn * 2 + j) * 32 + fr;
+                bf[cc][j] = *reinterpret_cast<const f32x4*>(Bs + row * 128 + ((ls ^ ((row >> 1) & 7)) << 4));
+            }
+        }
+        if (grp == 1 && h == NB - 1) wait_next(t);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- MFMA block, the DMA pieces of a later stage in its gaps
+        const bool my_issue = (grp == 0 ? h == 0 : h == NB - 1) && issued < T;
+        const int nbuf = issued % GL_NS;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int cc = 0; cc < CPB; ++cc)
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int g = (cc * TMW + i) * 2 + j;
+                    // piece q goes in front of MFMA (q * NMF) / NPW: spread evenly over the block
+                    if ((g * NPW) % NMF < NPW && (g * NPW) / NMF < NPW) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (my_issue) issue_piece(nbuf, (g * NPW) / NMF);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    acc[i][j] = g16_mfma(__builtin_bit_cast(op8, af[cc][i]), __builtin_bit_cast(op8, bf[cc][j]), acc[i][j]);
+                }
+        __builtin_amdgcn_s_setprio(0);
+        if (my_issue) ++issued;
+        if (grp == 0 && h == NB - 1) wait_next(t);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");          // the last slot: group 1's last MFMA block
+#else
     issue(0);
     if (AHEAD > 1 && T > 1) issue(1);
     for (int t = 0; t < T; ++t) {
@@ -183,6 +281,7 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
                 }
         }
     }
+#endif
     asm volatile("s_barrier" ::: "memory");       // every wave is done with the ring: the C tile may overwrite it
     __builtin_amdgcn_sched_barrier(0);
 
@@ -262,18 +361,18 @@ bool apse_conv_glds16_ok(const ConvParams& p) {
     return xbytes < 0xfffffff0ull && wbytes < 0xfffffff0ull;
 }
 
-template <int PR, int BN>
+template <int PR, int BM, int BN>
 static int launch_glds(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    const size_t lds_ring = (size_t)(BN == 128 ? 3 : 2) * (GL_BM + BN) * 128, lds_c = (size_t)GL_BM * (128 + 4) * sizeof(float);
+    const size_t lds_ring = (size_t)(BN == 128 ? 3 : 2) * (BM + BN) * 128, lds_c = (size_t)BM * (128 + 4) * sizeof(float);
     const size_t lds = lds_ring > lds_c ? lds_ring : lds_c;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_glds16<PR, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_glds16<PR, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    const int tiles = ((p.M + GL_BM - 1) / GL_BM) * ((p.Cout + BN - 1) / BN);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
     if (ev0) hipEventRecord(ev0, s);
-    hipLaunchKernelGGL((conv_glds16<PR, BN>), dim3(tiles), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((conv_glds16<PR, BM, BN>), dim3(tiles), dim3(512), lds, s, p);
     if (ev1) hipEventRecord(ev1, s);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
@@ -281,10 +380,17 @@ static int launch_glds(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEv
 // 256 x 256 tiles where they still give every CU about two tiles (N a multiple of 256: the filters are padded to 128 rows only)
 bool apse_conv_glds16_wide(const ConvParams& p) {
     static const bool off = getenv("APSE_GLDS_NARROW") != nullptr;        // A/B switch for the sweeps
-    return !off && (p.Cout & 255) == 0 && ((p.M + GL_BM - 1) / GL_BM) * (p.Cout / 256) >= 500;
+    return !off && (p.Cout & 255) == 0 && ((p.M + 255) / 256) * (p.Cout / 256) >= 500;
+}
+// 128 x 128 tiles (round 4) where 256-row tiles would leave CUs without work: fewer than ~0.8 tiles of 256 x 128 per CU
+// (res4 at batch 4: M = 16 128, N = 256 -> 126 tiles of 256 x 128 on 256 CUs, 252 of 128 x 128)
+bool apse_conv_glds16_small(const ConvParams& p) {
+    static const bool off = getenv("APSE_GLDS_NO128") != nullptr;         // A/B switch for the sweeps
+    return !off && ((p.M + 255) / 256) * ((p.Cout + 127) / 128) < 200;
 }
 
 int apse_launch_conv_glds16(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (apse_conv_glds16_wide(p)) return p.prec == 1 ? launch_glds<1, 256>(p, s, ev0, ev1) : launch_glds<2, 256>(p, s, ev0, ev1);
-    return p.prec == 1 ? launch_glds<1, 128>(p, s, ev0, ev1) : launch_glds<2, 128>(p, s, ev0, ev1);
+    if (apse_conv_glds16_wide(p)) return p.prec == 1 ? launch_glds<1, 256, 256>(p, s, ev0, ev1) : launch_glds<2, 256, 256>(p, s, ev0, ev1);
+    if (apse_conv_glds16_small(p)) return p.prec == 1 ? launch_glds<1, 128, 128>(p, s, ev0, ev1) : launch_glds<2, 128, 128>(p, s, ev0, ev1);
+    return p.prec == 1 ? launch_glds<1, 256, 128>(p, s, ev0, ev1) : launch_glds<2, 256, 128>(p, s, ev0, ev1);
 }

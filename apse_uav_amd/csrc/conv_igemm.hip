@@ -690,7 +690,14 @@ int apse_conv_effective_cfg(const ConvParams& p, int cfg) {
     if (!p.no_stream && apse_conv_skinny_ok(p)) return APSE_CFG_SKINNY;
     if (!p.no_stream && apse_conv1x1_stream_ok(p)) return APSE_CFG_STREAM;
     // wherever the 16-bit path would take the register-staged 256x128 tile, the LDS-DMA kernel of the same tile runs instead
-    if (!p.no_stream && fast16_shape(p, cfg) == 8 && apse_conv_glds16_ok(p)) return APSE_CFG_GLDS;     // (a caller forcing cfg 8 keeps the register-staged tile)
+    if (!p.no_stream && apse_conv_glds16_ok(p)) {
+        const int c16 = fast16_shape(p, cfg);
+        if (c16 == 8) return APSE_CFG_GLDS;                                  // (a caller forcing cfg 8 keeps the register-staged tile)
+        // round 4: deep-K layers with about ONE 128x128 tile per CU (res4 at batch 4, res5 at batch 8, fc1: 200..320 tiles) take the
+        // LDS-DMA kernel's 128x128 tile instead of the register-staged 128x64 / 128x128 ones
+        const int t128 = ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+        if ((c16 == 0 || c16 == 3) && p.steps_total >= 16 && t128 >= 200 && t128 <= 320 && apse_conv_glds16_small(p)) return APSE_CFG_GLDS;
+    }
     return cfg;
 }
 

@@ -62,6 +62,7 @@ int apse_k_closest_points(const uint64_t*, const int*, const int*, const unsigne
 int apse_k_closest_single(const uint64_t*, int, int, int, float, float, unsigned long long*, hipStream_t);
 int apse_k_undistort_gamma(const UndistortParams*, const uint8_t*, uint8_t*, const LabTables*, int, hipStream_t);
 int apse_k_bits_to_dense(const uint64_t*, const int*, int, int, int, uint8_t*, hipStream_t);
+int apse_k_copy_mask_windows(const uint64_t*, uint64_t*, int, const long long*, const long long*, const int*, const int*, int, hipStream_t);
 int apse_k_dense_to_bits(const uint8_t*, int, int, int, uint64_t*, unsigned long long*, hipStream_t);
 }
 
@@ -1196,6 +1197,24 @@ int apse_copy_mask_window(apse_ctx* c, int det, int x0, int y0, int x1, int y1, 
     HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)(w1 - w0) * 8, src, (size_t)c->wpr * 8, (size_t)(w1 - w0) * 8, (size_t)(y1 - y0),
                                hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return APSE_OK;
+}
+
+int apse_copy_mask_windows(apse_ctx* c, int n, const int* dets, const int* rects, uint64_t* dst, const long long* dst_off, void* stream) {
+    if (!c || !c->finalized) return fail(c, APSE_E_STATE, "not finalized");
+    const apse_config& g = c->cfg;
+    if (n < 0 || n > 100 || (n > 0 && (!dets || !rects || !dst || !dst_off))) return fail(c, APSE_E_INVALID, "bad mask windows");
+    long long src[100]; int nw[100], rows[100];
+    for (int k = 0; k < n; ++k) {
+        const int x0 = rects[k * 4], y0 = rects[k * 4 + 1], x1 = rects[k * 4 + 2], y1 = rects[k * 4 + 3];
+        if (dets[k] < 0 || dets[k] >= g.max_batch * g.dets_per_image || x0 < 0 || y0 < 0 || x1 > g.frame_w || y1 > g.frame_h || x1 <= x0 ||
+            y1 <= y0 || dst_off[k] < 0)
+            return fail(c, APSE_E_INVALID, "bad mask window");
+        const int w0 = x0 >> 6, w1 = (x1 + 63) >> 6;
+        src[k] = ((long long)dets[k] * g.frame_h + y0) * c->wpr + w0;
+        nw[k] = w1 - w0; rows[k] = y1 - y0;
+    }
+    int rc = apse_k_copy_mask_windows(c->bits2[c->bits_read], dst, n, src, dst_off, nw, rows, c->wpr, (hipStream_t)stream);
+    return rc ? fail(c, rc, "mask windows launch failed") : APSE_OK;
 }
 
 int apse_feature_shape(apse_ctx* c, const char* name, int* chw3) {

@@ -207,9 +207,36 @@ __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_ma
     }
 }
 
+// Boundary pixels of one 64-pixel word of a bit plane: mask pixels with at least one 4-neighbour outside the mask.  Rows outside
+// [ry0, ry1) and words outside [w0, w1) are outside the mask (the paste kernel writes exactly that window; bits of a window
+// word beyond the window's columns are written as zeros).  Bit b of a word is pixel x = 64 w + b.
+//
+// Why the closest point may be searched among these only (round 4; compute_closest_point, dcnn/utils/mask_utils.py:6-23: argmin of
+// the f32 value fl(fl(dx^2) + fl(dy^2)) in row-major order): the targets are integer pixel positions (floor centroids), so dx, dy
+// and their squares (< 2^24) are exact, and d = dx^2 + dy^2 is exact below 2^24 and rounded to a multiple of 2 in [2^24, 2^25).
+// Let P be an INTERIOR mask pixel (all four neighbours in the mask) other than the target, a = max(|dx|, |dy|) >= 1, and P' its
+// neighbour one step toward the target along that axis: d' = d - (2a - 1) exactly.  Below 2^24 both are exact integers, so
+// fl(d') < fl(d).  At d >= 2^24, a >= 2896, the decrease >= 5791 exceeds the rounding step (2) many times over: fl(d') < fl(d) again.
+// So an interior pixel is never the minimiser of (fl(d), row-major index) -- except the target pixel itself when it is a mask pixel
+// (d = 0, the unique smallest key), which the callers test directly.
+__device__ __forceinline__ uint64_t mt_boundary_word(const uint64_t* __restrict__ bits, int y, int w, int ry0, int ry1, int w0, int w1,
+                                                     int words_per_row) {
+    const uint64_t* row = bits + (size_t)y * words_per_row;
+    const uint64_t c = row[w];
+    if (!c) return 0ull;
+    const uint64_t up = y > ry0 ? row[w - words_per_row] : 0ull;
+    const uint64_t dn = y + 1 < ry1 ? row[w + words_per_row] : 0ull;
+    const uint64_t lw = w > w0 ? row[w - 1] : 0ull;
+    const uint64_t rw = w + 1 < w1 ? row[w + 1] : 0ull;
+    const uint64_t left = (c << 1) | (lw >> 63);          // bit b: pixel x - 1 is in the mask
+    const uint64_t right = (c >> 1) | (rw << 63);         // bit b: pixel x + 1 is in the mask
+    return c & ~(left & right & up & dn);
+}
+
 // closest[i][jl] for every detection i and every target jl of the same image.  Work item = (mask i,
-// band of `cb` window rows, picked like the paste launch's); each thread scans its words once per group of 8 targets and keeps 8
-// running minima of (f32 distance bits, row-major index); block minima are merged with atomicMin on
+// band of `cb` window rows, picked like the paste launch's); each thread scans the BOUNDARY pixels of its words (mt_boundary_word:
+// the minimiser is a boundary pixel, or the target itself when it lies on the mask -- tested in the epilogue) once per group of 8
+// targets and keeps 8 running minima of (f32 distance bits, row-major index); block minima are merged with atomicMin on
 // 64-bit keys (order-independent) IN the record's `closest` field; the host turns a key into 1-based (x, y) when it
 // has the record (apse_read_results_end).  Prologue (every block, one thread per detection): the band prefix and the
 // centroids -- centroid[i] = (floor(sum_x / mass), floor(sum_y / mass)) or (-1, -1) for an empty mask; block 0 writes
@@ -268,7 +295,7 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
             for (int t = threadIdx.x; t < nw * nrows; t += blockDim.x) {
                 const int ry = t / nw, w = w0 + (t - ry * nw);
                 const int y = yb + ry;
-                uint64_t word = bits[(size_t)y * words_per_row + w];
+                uint64_t word = mt_boundary_word(bits, y, w, ry0, ry1, w0, w1, words_per_row);
                 while (word) {
                     const int bit = __ffsll((long long)word) - 1;
                     word &= word - 1;
@@ -296,10 +323,34 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
                 if (j < j1 && j < nd && cent[j][0] >= 0) {
                     unsigned long long v = best[0][threadIdx.x];
                     for (int q = 1; q < 4; ++q) v = best[q][threadIdx.x] < v ? best[q][threadIdx.x] : v;
+                    // the target itself, when it is a pixel of this mask (possibly an interior one) in this band: distance 0
+                    const int tx = cent[j][0] - 1, ty = cent[j][1] - 1;
+                    if (ty >= yb && ty < yb + nrows && tx >= (w0 << 6) && tx < (w1 << 6) &&
+                        ((bits[(size_t)ty * words_per_row + (tx >> 6)] >> (tx & 63)) & 1ull)) {
+                        const unsigned long long self = (unsigned long long)(unsigned)(ty * out_w + tx);
+                        v = self < v ? self : v;
+                    }
                     if (v != ~0ull) atomicMin(keys + (size_t)i * kd + (j - j0), v);
                 }
             }
         }
+    }
+}
+
+// Mask windows of up to MW_MAX detections out of the bit planes in one launch (TrackRCNN.instances_from: the reference's
+// pred_masks of a frame; round 3 issued one 2-D copy per detection).  Window k: rows[k] rows of nw[k] words from src word offset
+// src[k] (row pitch = words_per_row) to dst word offset dst[k] (dense).  blockIdx.y = window.
+#define MW_MAX 100
+struct MaskWindows { long long src[MW_MAX], dst[MW_MAX]; int nw[MW_MAX], rows[MW_MAX]; };
+__global__ __launch_bounds__(256) void copy_mask_windows(const uint64_t* __restrict__ bits, uint64_t* __restrict__ out,
+                                                         const MaskWindows mw, int words_per_row) {
+    const int k = blockIdx.y;
+    const int nw = mw.nw[k], total = nw * mw.rows[k];
+    const uint64_t* s = bits + mw.src[k];
+    uint64_t* d = out + mw.dst[k];
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int r = t / nw, w = t - r * nw;
+        d[t] = s[(size_t)r * words_per_row + w];
     }
 }
 
@@ -336,15 +387,22 @@ __global__ __launch_bounds__(256) void dense_to_bits(const uint8_t* __restrict__
     if (lane == 0 && mass) { atomicAdd(sums, mass); atomicAdd(sums + 1, sx); atomicAdd(sums + 2, sy); }
 }
 
-// Closest point of ONE packed mask (full-frame rect) to an explicit target (stateless op for mask_utils).
+// Closest point of ONE packed mask (full-frame rect) to an explicit target (stateless op for mask_utils).  BOUNDARY: the target is
+// an integer pixel position -> the boundary-pixel search of the context's table kernel (same helper); any other target: every pixel.
+template <bool BOUNDARY>
 __global__ __launch_bounds__(256) void closest_point_single(const uint64_t* __restrict__ bits, int out_h, int out_w,
                                                             int words_per_row, float px, float py,
                                                             unsigned long long* __restrict__ best_out) {
     unsigned long long b = ~0ull;
     const int nwords = out_h * words_per_row;
+    if (BOUNDARY && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int tx = (int)px - 1, ty = (int)py - 1;                 // the target itself, when it is a mask pixel: distance 0
+        if (tx >= 0 && tx < out_w && ty >= 0 && ty < out_h && ((bits[(size_t)ty * words_per_row + (tx >> 6)] >> (tx & 63)) & 1ull))
+            b = (unsigned long long)(unsigned)(ty * out_w + tx);
+    }
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nwords; t += gridDim.x * blockDim.x) {
         const int y = t / words_per_row, w = t - y * words_per_row;
-        uint64_t word = bits[t];
+        uint64_t word = BOUNDARY ? mt_boundary_word(bits, y, w, 0, out_h, 0, words_per_row, words_per_row) : bits[t];
         const float dy = (float)(y + 1) - py;
         const float dy2 = dy * dy;
         while (word) {
@@ -365,7 +423,9 @@ extern "C" {
 int apse_k_closest_single(const uint64_t* bits, int out_h, int out_w, int words_per_row, float px, float py,
                           unsigned long long* best_out, hipStream_t s) {
     hipMemsetAsync(best_out, 0xff, sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(closest_point_single, dim3(512), dim3(256), 0, s, bits, out_h, out_w, words_per_row, px, py, best_out);
+    const bool integral = px == floorf(px) && py == floorf(py) && fabsf(px) < 16777216.f && fabsf(py) < 16777216.f;
+    if (integral) hipLaunchKernelGGL(closest_point_single<true>, dim3(512), dim3(256), 0, s, bits, out_h, out_w, words_per_row, px, py, best_out);
+    else hipLaunchKernelGGL(closest_point_single<false>, dim3(512), dim3(256), 0, s, bits, out_h, out_w, words_per_row, px, py, best_out);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_mask_paste(const PasteParams* p, int n_max, unsigned long long* keys, int kd, hipStream_t s) {
@@ -380,6 +440,21 @@ int apse_k_closest_points(const uint64_t* bits, const int* rect, const int* vali
     if (n_max <= 0) return APSE_OK;
     hipLaunchKernelGGL(closest_points, dim3(1024), dim3(256), 0, s, bits, rect, valid, sums, img, offset, total, n_max, kd, out_h,
                        out_w, words_per_row, keys, cent, mass);
+    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
+}
+int apse_k_copy_mask_windows(const uint64_t* bits, uint64_t* out, int n, const long long* src, const long long* dst, const int* nw,
+                             const int* rows, int words_per_row, hipStream_t s) {
+    if (n <= 0) return APSE_OK;
+    if (n > MW_MAX) return APSE_E_INVALID;
+    MaskWindows mw;
+    int most = 1;
+    for (int k = 0; k < n; ++k) {
+        mw.src[k] = src[k]; mw.dst[k] = dst[k]; mw.nw[k] = nw[k]; mw.rows[k] = rows[k];
+        most = nw[k] * rows[k] > most ? nw[k] * rows[k] : most;
+    }
+    int gx = (most + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(copy_mask_windows, dim3(gx, n), dim3(256), 0, s, bits, out, mw, words_per_row);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_bits_to_dense(const uint64_t* bits, const int* rect4, int out_h, int out_w, int words_per_row, uint8_t* dense,

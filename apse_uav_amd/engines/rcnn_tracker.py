@@ -13,8 +13,6 @@ closest points) runs in ``libapse_hip.so``; the sequential id bookkeeping stays 
 ``next_record`` drives the same association from a per-frame record, which is what rank 0
 does with the records gathered from the other GPUs in frame-sharded mode.
 """
-import ctypes as C
-
 import numpy as np
 import torch
 from scipy.optimize import linear_sum_assignment
@@ -77,10 +75,10 @@ class RcnnTracker:
         self.frame_count += 1
         return self._finish_frame(instances_from_record(record, self.image_size, self.device), None, host_replay=True)
 
-    def _finish_frame(self, detections, backbone_features, host_replay=False):
+    def _finish_frame(self, detections, backbone_features, host_replay=True):
+        """``host_replay`` is accepted for older callers; since round 4 the record path always associates on the host."""
         self._last_record = getattr(detections, "_record", None)
         self._obj_det = {}
-        self._host_replay = host_replay
         self.associate_detections_to_objects(detections, backbone_features=backbone_features, metric='embeddings')
         self.objects.delete_undetected_objects(self.OBJECT_UNDETECTED_FRAMES_TH)
         if 'objects' in self.DISPLAY_INFO: print(self.objects)
@@ -95,30 +93,16 @@ class RcnnTracker:
         if metric != 'embeddings':
             raise NotImplementedError("only the 'embeddings' metric is live in the reference (rcnn_tracker.py:69)")
         if len(detections) > 0:
-            # the device part of the association (embeddings H2D, distance-matrix kernel, its D2H) runs on a stream of its own: on
-            # the predictor's stream the `.cpu()` in there would wait for everything enqueued -- with an announced next frame that is
-            # the next frame's whole network (TrackPredictor run-ahead).  Same kernel, same arithmetic.
-            # (only the record path: features handed in by a caller live on the caller's stream)
-            import contextlib
-            with (self._assoc_ctx() if getattr(detections, "_record", None) is not None else contextlib.nullcontext()):
-                self._associate(detections, backbone_features)
-
-    def _assoc_ctx(self):
-        import contextlib
-        if self.device.type != "cuda" or getattr(self, "_host_replay", False) or not torch.cuda.is_available():
-            return contextlib.nullcontext()
-        if getattr(self, "_assoc_stream", None) is None:
-            self._assoc_stream = torch.cuda.Stream(device=self.device)
-        return torch.cuda.stream(self._assoc_stream)
+            self._associate(detections, backbone_features)
 
     def _associate(self, detections, backbone_features):
         rec = getattr(detections, "_record", None)
         if rec is not None:
-            # embeddings already computed by the fused GPU stage; kept on the host: the sequential
-            # association (this method) is host work, also on rank 0 of a sharded run
+            # embeddings already computed by the fused GPU stage and delivered with the results block; they stay on the host: the
+            # sequential association (this method) is host work -- O x N x 128 flops -- in next_frame as on rank 0 of a sharded run
+            # (SURVEY 8e).  Round 3 sent them back to the GPU for the distance matrix (H2D -> apse_sqdist -> .cpu(): ~0.15 ms of
+            # round trips per frame behind the results copy); calculate_distance_matrix still runs the kernel for device tensors.
             detection_embeddings = torch.from_numpy(np.ascontiguousarray(rec["embeddings"]))
-            if not getattr(self, "_host_replay", False):
-                detection_embeddings = detection_embeddings.to(self.device)     # next_frame: distance matrix on the GPU
         else:
             rois = self.get_features_rois(detections, backbone_features, crop_features=self.crop_features)
             detection_embeddings = self.association_head(rois)

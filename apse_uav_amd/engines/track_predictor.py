@@ -21,26 +21,19 @@ from ..networks.track_rcnn import TrackRCNN
 from ..weights import load_detector_file
 
 
-_COPY_POOL = None
-_COPY_THREADS = max(1, int(os.environ.get("APSE_STAGE_THREADS", "4")))       # host threads of the staging copy (tools/entry_probe.py sweeps it)
+_COPY_THREADS = max(1, int(os.environ.get("APSE_STAGE_THREADS", "8")))       # host threads of the staging copy (tools/entry_probe.py sweeps it)
 
 
 def _host_copy(dst, src):
-    """dst[...] = src for HxWx3 uint8 arrays (25 MB at 4K) on a few plain threads (numpy releases the GIL for the copy).
-    Deliberately NOT a torch op: torch's intra-op pool (OpenMP) spins after a parallel region, and under a container CPU
-    quota those spinning workers get the whole process throttled for tens of milliseconds every few frames."""
-    global _COPY_POOL
-    n = dst.shape[0]
-    if dst.nbytes < (4 << 20) or n < 8:
-        np.copyto(dst, src)
+    """dst[...] = src for HxWx3 uint8 arrays (25 MB at 4K).  Contiguous rows go through ``apse_host_copy`` (csrc/host_stage.hip: a
+    persistent pool of plain threads inside the library; ctypes releases the GIL for the call); a strided source (the RGB flip)
+    is left to numpy.  Deliberately NOT a torch op: torch's intra-op pool (OpenMP) spins after a parallel region, and under a
+    container CPU quota those spinning workers get the whole process throttled for tens of milliseconds every few frames."""
+    if src.flags["C_CONTIGUOUS"] and dst.flags["C_CONTIGUOUS"] and src.dtype == dst.dtype and src.shape == dst.shape:
+        from .. import _lib
+        _lib.check(_lib.load().apse_host_copy(dst.ctypes.data, src.ctypes.data, dst.nbytes, _COPY_THREADS), None, "apse_host_copy")
         return
-    if _COPY_POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _COPY_POOL = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="apse-stage")
-    step = (n + _COPY_THREADS - 1) // _COPY_THREADS
-    futs = [_COPY_POOL.submit(np.copyto, dst[lo:lo + step], src[lo:lo + step]) for lo in range(0, n, step)]
-    for f in futs:
-        f.result()
+    np.copyto(dst, src)
 
 
 class _Slot:

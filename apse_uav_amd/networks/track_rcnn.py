@@ -312,14 +312,28 @@ class TrackRCNN:
         inst.pred_classes = torch.from_numpy(rec["classes"])
         masks = MaskList()
         lib = _lib.load()
+        rects = np.ascontiguousarray(rec["rects"], np.int32).reshape(n, 4)
+        # every window of the frame out of the bit planes with ONE launch into one pooled buffer (views per detection);
+        # more than 100 detections cannot occur per image (TEST.DETECTIONS_PER_IMAGE <= 100)
+        live = [k for k in range(n) if want_masks and rects[k, 2] > rects[k, 0] and rects[k, 3] > rects[k, 1]]
+        pool, offs = None, {}
+        if live:
+            nw = ((rects[live, 2] + 63) >> 6) - (rects[live, 0] >> 6)
+            words = nw.astype(np.int64) * (rects[live, 3] - rects[live, 1])
+            off = np.zeros(len(live) + 1, np.int64)
+            np.cumsum(words, out=off[1:])
+            pool = torch.empty((int(off[-1]),), dtype=torch.int64, device=self.device)
+            dets = np.ascontiguousarray(rec["packed_index"][live], np.int32)
+            lrects = np.ascontiguousarray(rects[live])
+            _lib.check(lib.apse_copy_mask_windows(self._ctx, len(live), _lib.ptr(dets), _lib.ptr(lrects), _lib.ptr(pool),
+                                                  _lib.ptr(np.ascontiguousarray(off[:-1])), _lib.stream_ptr()), self._ctx, "apse_copy_mask_windows")
+            offs = {k: (int(off[j]), int(off[j + 1]), int(nw[j])) for j, k in enumerate(live)}
         for k in range(n):
-            x0, y0, x1, y1 = [int(v) for v in rec["rects"][k]]
+            x0, y0, x1, y1 = [int(v) for v in rects[k]]
             bits = None
-            if want_masks and x1 > x0 and y1 > y0:
-                nw = ((x1 + 63) >> 6) - (x0 >> 6)
-                bits = torch.empty((y1 - y0, nw), dtype=torch.int64, device=self.device)
-                _lib.check(lib.apse_copy_mask_window(self._ctx, int(rec["packed_index"][k]), x0, y0, x1, y1, _lib.ptr(bits),
-                                                     _lib.stream_ptr()), self._ctx, "apse_copy_mask_window")
+            if k in offs:
+                lo, hi, w = offs[k]
+                bits = pool[lo:hi].view(y1 - y0, w)
             masks.append(WindowMask(bits, (x0, y0, x1, y1), frame_hw, rec["centroids"][k], rec["mass"][k]))
         inst.pred_masks = masks
         inst._record = rec

@@ -159,6 +159,10 @@ int apse_read_results_end(apse_ctx* ctx, void* host_dst);
 /* Copies detection i's mask window (rows rect.y0..y1, 64-bit words (x0>>6)..((x1+63)>>6)) to dst_dev: the masks of the forward whose
  * results were last read (apse_read_results / _begin), or of the last forward when no read has been started since. */
 int apse_copy_mask_window(apse_ctx* ctx, int det, int x0, int y0, int x1, int y1, uint64_t* dst_dev, void* stream);
+/* The same for n detections in ONE launch (n <= 100): window k = detection dets[k], rect rects[k] = x0,y0,x1,y1, written as
+ * (y1 - y0) rows of ((x1 + 63) >> 6) - (x0 >> 6) words at dst_dev + dst_word_offsets[k].  Host arrays, read before the call returns. */
+int apse_copy_mask_windows(apse_ctx* ctx, int n, const int* dets_host, const int* rects_host, uint64_t* dst_dev,
+                           const long long* dst_word_offsets_host, void* stream);
 /* Named internal tensor -> caller buffer as NCHW f32 (p2..p6, res2..res5, stem): the feature dict
  * TrackRCNN.inference returns (track_rcnn.py:57-58).  dims (B,C,H,W) via apse_feature_shape. */
 int apse_feature_shape(apse_ctx* ctx, const char* name, int* chw3);
@@ -253,6 +257,12 @@ long long apse_replay_packed(apse_replay* r, const float* records_host, long lon
                              int first_frame, char* lines_out, long long cap);
 int apse_replay_max_id(const apse_replay* r);
 int apse_replay_next_id(const apse_replay* r);
+
+
+/* ---- host-only: staging copy of the ingest path.  memcpy(dst, src, bytes) split over a small persistent pool of threads
+ * (the caller's thread takes one part): a pageable frame from cv2.VideoCapture.read (visualize_uav.py:188-191) into the pinned
+ * buffer its H2D starts from.  threads <= 1 or < 1 MB: plain memcpy.  Calls are serialised. */
+int apse_host_copy(void* dst, const void* src, size_t bytes, int threads);
 
 #ifdef __cplusplus
 }

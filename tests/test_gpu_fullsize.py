@@ -654,10 +654,14 @@ def test_given_boxes_sequence64_ids_16bit_vs_f32_vs_oracle(env, logdir, golden_d
         json.dump(table, f, indent=1)
     _log(logdir, "given_boxes_seq64", table)
     a = table["f32_b1_vs_oracle"]
+    # [round 4, MI355X: f32 vs the oracle 64 / 64 frames with the same ids, 64 / 64 identical CSV lines, 0 of 1 200 numeric cells differ,
+    #  80 blank cells; bf16 batch 4 + undistort / gamma vs f32 on the same input: ids 64 / 64, centroids within 7 px, closest points
+    #  within 245 px (a closest point slides along a mask edge when an edge pixel flips); fp16 batch 8: ids 64 / 64, 3 px / 35 px]
     assert a["frames_same_ids"] == 64 and a["blank_pattern_equal"] and a["blank_cells"] >= 40, a
-    assert a["identical_csv_lines"] >= 56 and a["centroid_delta_max_px"] <= 2, a        # bars set from the first observation, see DESIGN 5
-    for tag in ("bf16_b4_preproc_vs_f32_preproc", "f16_b8_vs_f32"):
+    assert a["identical_csv_lines"] == 64 and a["differing_cells"] == 0, a
+    for tag, cent_bar, clos_bar in (("bf16_b4_preproc_vs_f32_preproc", 14, 490), ("f16_b8_vs_f32", 6, 70)):      # 2x the observation
         assert table[tag]["frames_same_ids"] == 64 and table[tag]["blank_pattern_equal"], (tag, table[tag])
+        assert table[tag]["centroid_delta_max_px"] <= cent_bar and table[tag]["closest_delta_max_px"] <= clos_bar, (tag, table[tag])
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])

@@ -56,6 +56,11 @@ CONV_CASES = [
     ("g_3x3_s2", 1, 128, 27, 33, 136, 3, 2, 1, False, 0, 11, 0),
     ("g_fc7x7", 37, 256, 7, 7, 1024, 7, 1, 0, True, 0, 11, 0),
     ("g_wide_256x256", 1, 64, 361, 359, 256, 3, 1, 1, True, 1, 11, 0),      # >= 500 tiles of 256x256: the two-stage wide-tile variant
+    # round 4: the kernel picks its 128x128 tile below 200 tiles of 256x128 (every case above but the wide one) and 256x128 from there on
+    ("g_256x128_many", 1, 64, 230, 231, 128, 3, 1, 1, True, 1, 11, 0),      # 208 tiles of 256x128, ragged last tile, residual
+    ("g_256x128_1x1_k512", 1, 512, 228, 230, 136, 1, 1, 0, False, 0, 11, 0),  # 8 stages, Cout not a multiple of the tile (2 x 205 tiles)
+    ("g_128x128_two_stages", 2, 128, 31, 29, 256, 1, 1, 0, True, 1, 11, 0),   # T = 2: prologue and drain of the ping-pong loop only
+    ("g_128x128_one_stage", 1, 64, 40, 44, 128, 1, 1, 0, False, 0, 11, 0),    # T = 1
 ]
 
 
@@ -140,6 +145,11 @@ def test_conv2d_16bit_storage(case, prec, logdir):
     frac = float((diff > 1e-6 * ref.abs().clamp_min(1.0)).float().mean())
     _log(logdir, "conv_16bit_storage/%d/" % prec + name, dict(max=float(diff.max()), frac_differs=frac))
     assert bool((diff <= tol).all()) and frac < 0.02
+    if cfg == 11:
+        # the LDS-DMA kernel (any of its tiles, ping-pong schedule) runs the MFMA chain of the register-staged tiles: same bits
+        tiled = hip_conv2d(x, w, b, stride, pad, relu, res, res_mode, 0, splitk, prec=prec, x_st=prec, res_st=prec if res is not None else 0,
+                           y_st=prec)
+        assert torch.equal(out, tiled), name
     # f32-compute kernel reading 16-bit activations (decision layers in 16-bit storage mode)
     if cfg in (-1, 2) and res_mode == 0:
         out32 = hip_conv2d(x, w, b, stride, pad, relu, None, 0, cfg, splitk, prec=0, x_st=prec)
@@ -513,6 +523,58 @@ def test_mask_utils_golden(golden_dir, logdir):
                 assert cen[axis] - c["centroid"][axis] in (0.0, 1.0), c["name"]
             else:
                 assert cen[axis] == c["centroid"][axis], c["name"]
+
+
+def test_closest_point_boundary_search_equals_full_scan(logdir):
+    """Round 4: the closest-point kernels look at BOUNDARY pixels only (mask pixels with a 4-neighbour outside the mask; the target
+    pixel itself is tested directly) -- csrc/mask_tail.hip mt_boundary_word carries the argument why the minimiser of
+    (f32 distance, row-major index) is among them for integer targets.  Random masks -- blobs, blobs with holes, 30 % speckle (nearly
+    every pixel is boundary), word-aligned edges, masks touching the frame border -- and integer targets outside the mask, on
+    interior pixels, on boundary pixels, inside holes, and > 4096 px away (f32 distances above 2^24: rounding ties) against the
+    oracle's full row-major argmin (compute_closest_point restated, dcnn/utils/mask_utils.py:6-23); one non-integer target takes the
+    full-scan kernel."""
+    from apse_uav_amd.utils import mask_utils
+    from oracle import mask_utils as omu
+    H, W = 2160, 3840
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:H, 0:W]
+    checked = 0
+    for case in range(6):
+        m = np.zeros((H, W), bool)
+        if case < 4:
+            for _ in range(int(rng.integers(1, 5))):
+                cx, cy = rng.integers(0, W), rng.integers(0, H)
+                rx, ry = rng.integers(20, 400), rng.integers(20, 300)
+                m |= ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 <= 1.0
+            if case >= 2:                                        # holes
+                for _ in range(6):
+                    ys, xs = np.nonzero(m)
+                    k = rng.integers(0, len(ys))
+                    m[max(ys[k] - 9, 0):ys[k] + 9, max(xs[k] - 14, 0):xs[k] + 14] = False
+        elif case == 4:                                          # speckle inside a word-aligned rectangle
+            m[700:1100, 1280:1920] = rng.random((400, 640)) < 0.3
+        else:                                                    # far corner blob: distances > 2^24 from targets near (1, 1)
+            m |= ((xx - 3700) / 111) ** 2 + ((yy - 2040) / 90) ** 2 <= 1.0
+            m[2100:2160, 3600:3840] = True
+        ys, xs = np.nonzero(m)
+        x0, y0, x1, y1 = int(xs.min()), int(ys.min()), int(xs.max()) + 1, int(ys.max()) + 1
+        win, rect = m[y0:y1, x0:x1], (x0, y0, x1, y1)
+        md = torch.from_numpy(m).cuda()
+        targets = [(1.0, 1.0), (3840.0, 2160.0), (3.0, 5.0), (float(W // 2), float(H // 2))]
+        for _ in range(10):
+            k = rng.integers(0, len(ys))
+            targets.append((float(xs[k] + 1), float(ys[k] + 1)))                            # on the mask (interior or boundary)
+            targets.append((float(rng.integers(1, W + 1)), float(rng.integers(1, H + 1))))  # anywhere
+        holes = np.argwhere(~win)
+        for k in rng.integers(0, max(len(holes), 1), 4 if len(holes) else 0):
+            targets.append((float(holes[k][1] + 1 + x0), float(holes[k][0] + 1 + y0)))      # non-mask pixel inside the window (holes)
+        targets.append((1911.5, 966.25))                                                    # not a pixel position: full-scan kernel
+        for t in targets:
+            got = mask_utils.compute_closest_point(md, t)
+            ref = omu.window_closest_point(win, rect, t)
+            assert got == ref, (case, t, got, ref)
+            checked += 1
+    _log(logdir, "closest_boundary_vs_full", dict(cases=6, targets=checked))
 
 
 def test_association_head_golden(golden_dir, logdir):

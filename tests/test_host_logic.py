@@ -318,3 +318,17 @@ def test_integer_lab_gamma_against_the_f32_formulas():
     out = op.lab_gamma(grey, op.gamma_lut())
     assert np.all(np.diff(out[0, :, 0].astype(np.int32)) >= 0) and out[0, 255, 0] >= 254 and out[0, 0, 0] == 0      # grey ramp stays monotone
     assert np.abs(out[..., 0].astype(np.int32) - out[..., 1]).max() <= 1 and np.abs(out[..., 1].astype(np.int32) - out[..., 2]).max() <= 1
+
+
+def test_host_copy_pool_equals_memcpy():
+    """csrc/host_stage.hip: the ingest path's staging copy on the library's thread pool (FrameUploader) -- sizes below the
+    threading floor, odd sizes, a 4K frame, repeated calls with different thread counts."""
+    from apse_uav_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    for nbytes, threads in ((0, 4), (17, 4), ((1 << 20) + 13, 3), (2160 * 3840 * 3, 8), (2160 * 3840 * 3, 1), (5 << 20, 32), (3 << 20, 2)):
+        src = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        dst = np.zeros(nbytes + 64, np.uint8)
+        assert lib.apse_host_copy(dst.ctypes.data, src.ctypes.data, nbytes, threads) == 0
+        assert np.array_equal(dst[:nbytes], src) and not dst[nbytes:].any()
+    assert lib.apse_host_copy(None, None, 5, 2) < 0
