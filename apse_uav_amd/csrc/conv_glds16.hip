@@ -22,9 +22,6 @@ typedef _Float16 g16_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 g16_mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 g16_mfma(g16_f16x8 a, g16_f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-#ifndef GL_PP
-#define GL_PP 1          // 1: ping-pong schedule of the two wave groups (round 4, below); 0: the round-2 loop (A/B builds)
-#endif
 #ifndef GL_ABLATE
 #define GL_ABLATE 0      // diagnostics only (tools/gpu_glds_ablate.sh): 1 no MFMA, 2 DMAs of the first two stages only, 3 no fragment reads, 4 two of three A fetches out of range
 #endif
@@ -36,22 +33,13 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // columns.  128 x 128 (round 4): 8 waves as 4 x 2, 32 x 64 per wave, three stages of 32 KB -- for the layers whose M gives about
 // one 128 x 128 tile per CU but only half a wave of 256-row tiles (res4 at batch 4: M = 16 128, N = 256 -> 252 tiles).
 //
-// Ping-pong schedule (GL_PP, round 4).  The round-2 loop let all eight waves do the same thing at the same time: after each
-// stage's barrier every wave first issued fragment reads (matrix pipe idle), then every wave issued MFMAs (LDS idle); the SQ
-// counters showed the pipe busy 27-43 % with both the LDS side and the MFMA side about a stage long.  Now the waves form two
-// groups -- waves 0..3 and 4..7, one of each per SIMD -- that alternate in opposite phase: a stage is cut into NB blocks of CPB
-// k-chunks; a wave READS all fragments of a block (ds_read_b128 only), passes a barrier, then issues the block's MFMAs back to
-// back (s_setprio 1, the LDS-DMA pieces of a later stage riding in the gaps), passes a barrier, and so on; group 1 runs exactly one
-// slot behind group 0, so in every slot one wave of each SIMD is in its MFMA block while the other reads.  Slots (every boundary is
-// one workgroup barrier): group 0 READ(u) in slot 2u, MFMA(u) in 2u + 1; group 1 READ(u) in 2u + 1, MFMA(u) in 2u + 2.
-//   * WAR: stage X lands in the buffer of stage X - NS, last read by group 1 in slot 2 NB (X - AHEAD) - 1 (NS = AHEAD + 1); group 0
-//     issues its pieces of stage t + AHEAD in the MFMA block of the FIRST block of stage t (slot 2 NB t + 1), group 1 its pieces of
-//     stage t + 1 + AHEAD in the MFMA block of the LAST block of stage t (slot 2 NB (t + 1)) -- both behind that barrier;
-//   * RAW: stage X is first read by group 0 in slot 2 NB X.  In the slot before, group 0 is in the MFMA block and group 1 in the
-//     READ block of the last block of stage X - 1: each ends it with a counted s_waitcnt vmcnt that leaves only its own pieces of
-//     LATER stages outstanding ((AHEAD - 1) NPW), then the barrier: every wave's share of stage X is retired by its issuer before
-//     a barrier every reader passes (cdna_hip_programming.md "read a staged buffer one phase AFTER the wait that retires it").
-// Same MFMA instruction, same k order per accumulator as before: results are bit-identical to the round-2 loop (tests).
+// Built, measured and dropped (round 4): a ping-pong schedule -- the eight waves as two groups (one wave of each per SIMD) in
+// opposite phase, a block of fragment reads / a barrier / the block's MFMAs back to back with s_setprio 1 / a barrier, group 1 one
+// slot behind group 0, counted vmcnt at the stage seams (bit-identical, race-screened by the equality tests).  On one box, old
+// loop -> ping-pong, us per launch: 256x256 300 -> 325 (fp16 batch 8) and 320 -> 355 (bf16 batch 4); 256x128 42.7 -> 51.7 and
+// 37.0 -> 44.5; 128x128 25.1 -> 26.2 (profiles/r04b_kstats_pingpong.txt).  With 8 or 16 MFMAs per block the four barriers per
+// stage and the exposed ds_read latency in front of each MFMA block cost more than the forced alternation gains: two free-running
+// waves per SIMD already overlap one wave's reads with the other's MFMAs.
 template <int PR, int GL_BM, int GL_BN>
 __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
     typedef typename std::conditional<PR == 1, bf16x8, g16_f16x8>::type op8;
@@ -155,90 +143,13 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
     constexpr int AHEAD = GL_NS - 1;                  // stages in flight beyond the one being computed
-#if GL_PP
-    constexpr int CPB = GL_BM == 128 ? 4 : 2;         // k-chunks (16 deep) per block: 8 / 8 / 16 MFMAs per block and wave
-    constexpr int NB = 4 / CPB;                       // blocks per 64-deep stage
-    constexpr int NMF = CPB * TMW * 2;                // MFMAs of a block
-    static_assert(NB == 2 || AHEAD >= 2, "one block per stage needs two stages in flight (the wait follows the issue in one block)");
-    static_assert(NPW <= NMF, "a stage's DMA pieces ride in the gaps of ONE MFMA block");
-    const int grp = wave >> 2;                        // waves w and w + 4 share a SIMD: one of each group per SIMD
-    const int U = T * NB;
-    int issued = 0;                                   // stages this wave has issued its pieces of
-    // group 1 runs one stage further ahead (its issue point is the block BEFORE group 0's, see above)
-    for (; issued < T && issued < AHEAD + grp; ++issued) issue(issued % GL_NS);
-    // stage 0 complete for this wave, leaving its later prologue stages in flight; then the barrier that vouches for all waves
-    if (issued <= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (issued == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
-    asm volatile("s_barrier" ::: "memory");
-    if (grp == 1) asm volatile("s_barrier" ::: "memory");          // slot 0: group 0 reads block 0
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 af[CPB][TMW], bf[CPB][2];
-    // the wait that retires stage t + 1 for this wave (at the end of the last block of stage t: group 0 behind its MFMAs, group 1
-    // behind its reads).  By then the wave has issued stages up to `issued - 1`; those beyond t + 1 may stay in flight.
-    auto wait_next = [&](int t) {
-        const int later = issued - (t + 2);           // own stages issued beyond t + 1: 0 .. AHEAD - 1 (+ 0 for group 1: same count, see header)
-        if (later <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
-    };
-    static_assert(AHEAD <= 2, "wait_next distinguishes 0 or 1 later stages");
-    for (int u = 0; u < U; ++u) {
-        const int t = u / NB, h = u - t * NB;
-        const char* As = smem + (t % GL_NS) * GL_STAGE;
-        const char* Bs = As + GL_BM * 128;
-        // ---------------- READ block: every fragment of CPB chunks
-#pragma unroll
-        for (int cc = 0; cc < CPB; ++cc) {
-            const int ls = 2 * (h * CPB + cc) + fh;
-#pragma unroll
-            for (int i = 0; i < TMW; ++i) {
-                const int row = (wm * TMW + i) * 32 + fr;
-                af[cc][i] = *reinterpret_cast<const f32x4*>(As + row * 128 + ((ls ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = (wn * 2 + j) * 32 + fr;
-                bf[cc][j] = *reinterpret_cast<const f32x4*>(Bs + row * 128 + ((ls ^ ((row >> 1) & 7)) << 4));
-            }
-        }
-        if (grp == 1 && h == NB - 1) wait_next(t);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // ---------------- MFMA block, the DMA pieces of a later stage in its gaps
-        const bool my_issue = (grp == 0 ? h == 0 : h == NB - 1) && issued < T;
-        const int nbuf = issued % GL_NS;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int cc = 0; cc < CPB; ++cc)
-#pragma unroll
-            for (int i = 0; i < TMW; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int g = (cc * TMW + i) * 2 + j;
-                    // piece q goes in front of MFMA (q * NMF) / NPW: spread evenly over the block
-                    if ((g * NPW) % NMF < NPW && (g * NPW) / NMF < NPW) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (my_issue) issue_piece(nbuf, (g * NPW) / NMF);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    acc[i][j] = g16_mfma(__builtin_bit_cast(op8, af[cc][i]), __builtin_bit_cast(op8, bf[cc][j]), acc[i][j]);
-                }
-        __builtin_amdgcn_s_setprio(0);
-        if (my_issue) ++issued;
-        if (grp == 0 && h == NB - 1) wait_next(t);
-        asm volatile("s_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (grp == 0) asm volatile("s_barrier" ::: "memory");          // the last slot: group 1's last MFMA block
-#else
     issue(0);
     if (AHEAD > 1 && T > 1) issue(1);
     for (int t = 0; t < T; ++t) {
         // stage t has landed once this wave's DMAs of the later stages are the only ones outstanding; the barrier then vouches for
         // every wave's share and for the end of all reads of stage t - 1, whose buffer stage t + AHEAD is about to overwrite
         if (GL_ABLATE == 2 || AHEAD == 1 || t + 1 >= T) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // BN = 128: NPW = 6 pieces of stage t + 1 may stay in flight
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");   // three stages: the NPW pieces of stage t + 1 may stay in flight
         asm volatile("s_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         const bool more = (t + AHEAD < T) && (GL_ABLATE != 2);
@@ -281,7 +192,6 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
                 }
         }
     }
-#endif
     asm volatile("s_barrier" ::: "memory");       // every wave is done with the ring: the C tile may overwrite it
     __builtin_amdgcn_sched_barrier(0);
 

@@ -27,7 +27,7 @@ struct PasteParams {
 extern "C" {
 int apse_k_pil_resize(const uint8_t*, uint8_t*, void*, int, uint8_t*, const int*, const int*, int, const int*, const int*, int, int,
                       int, int, int, int, int, int, const float*, const UndistortParams*, const LabTables*, const void*, const int*, int, hipStream_t);
-int apse_k_undistort_build_map(const UndistortParams*, void*, hipStream_t);
+int apse_k_undistort_build_map_compact(const UndistortParams*, void*, int*, hipStream_t);
 int apse_k_chw_norm(const float*, void*, int, int, int, int, int, int, const float*, hipStream_t);
 int apse_k_maxpool3x3s2(const void*, void*, int, int, int, int, int, hipStream_t);
 bool apse_assoc_fc_ok(int K, int N);
@@ -122,7 +122,7 @@ struct apse_ctx {
     float* ws_assoc = nullptr;      // [K / 128][max detections][embed_dim]: K slices of the association FC (apse_k_assoc_fc), or nullptr
     float* rf_mask = nullptr; size_t rf_mask_floats = 0;      // apse_roi_features: masks at p2 resolution (grown on demand)
     bool box_maxc_clean = false;
-    UndistortParams cam; bool cam_on = false; LabTables* cam_lut = nullptr; void* cam_map = nullptr;     // apse_set_camera: fused undistort + gamma in apse_preprocess_frames
+    UndistortParams cam; bool cam_on = false; LabTables* cam_lut = nullptr; void* cam_map = nullptr; bool cam_map_ok = false;     // apse_set_camera: fused undistort + gamma in apse_preprocess_frames
     int hint_total = 8;      // detections seen in the previous forward: sizes the GRID of the packed-list GEMMs, nothing else
     hipEvent_t read_ev = nullptr; void* read_pending = nullptr;      // apse_read_results_begin / _end
     // apse_set_detections: two pinned staging blocks, each guarded by the event behind its H2D copies, so the call only enqueues
@@ -888,7 +888,7 @@ int apse_preprocess_frames(apse_ctx* c, const uint8_t* frames, int batch, void* 
     if (!c->hb) return fail(c, APSE_E_STATE, "resize tables not set");
     const apse_config& g = c->cfg;
     int rc = apse_k_pil_resize(frames, c->rs_tmp, c->t["input"].p, c->t["input"].st, nullptr, c->hb, c->hc, c->hk, c->vb, c->vc, c->vk, batch,
-                               g.frame_h, g.frame_w, g.image_h, g.image_w, c->PH, c->PW, g.pixel_mean, c->cam_on ? &c->cam : nullptr, c->cam_lut, c->cam_map,
+                               g.frame_h, g.frame_w, g.image_h, g.image_w, c->PH, c->PW, g.pixel_mean, c->cam_on ? &c->cam : nullptr, c->cam_lut, c->cam_map_ok ? c->cam_map : nullptr,
                                c->hcT, c->rs_pitch, (hipStream_t)stream);
     return rc ? fail(c, rc, "pil resize launch failed") : APSE_OK;
 }
@@ -1592,13 +1592,23 @@ int apse_set_camera(apse_ctx* c, const double* m, const double* dist, int ndist,
         HIPCHK(c, hipDeviceSynchronize());
         HIPCHK(c, hipMemcpy(c->cam_lut, &host, sizeof(LabTables), hipMemcpyHostToDevice));
     }
-    // the remap table depends on the camera only: built here once (f64 rational model per pixel), read per frame (8 B per pixel)
-    if (!c->cam_map) {
-        c->cam_map = dalloc<uint64_t>(c, (size_t)c->cfg.frame_h * c->cfg.frame_w, false);
-        if (!c->cam_map) return fail(c, APSE_E_NOMEM, "camera map alloc");
+    // the remap table depends on the camera only: built here once (f64 rational model per pixel), read per frame -- 4 bytes per
+    // pixel: the source position relative to the pixel in 1/32 px (preproc_pixel.h).  A camera that displaces a pixel inside the
+    // frame by 1024 px or more does not fit; it keeps the per-pixel model (slower, same bytes).
+    c->cam_map_ok = false;
+    if (do_undistort) {
+        if (!c->cam_map) {
+            c->cam_map = dalloc<uint32_t>(c, (size_t)c->cfg.frame_h * c->cfg.frame_w + 4, false);
+            if (!c->cam_map) return fail(c, APSE_E_NOMEM, "camera map alloc");
+        }
+        int* ovf = reinterpret_cast<int*>(reinterpret_cast<uint32_t*>(c->cam_map) + (size_t)c->cfg.frame_h * c->cfg.frame_w);
+        HIPCHK(c, hipMemset(ovf, 0, sizeof(int)));
+        rc = apse_k_undistort_build_map_compact(&p, c->cam_map, ovf, nullptr);
+        if (rc) return fail(c, rc, "camera map launch failed");
+        int overflow = 0;
+        HIPCHK(c, hipMemcpy(&overflow, ovf, sizeof(int), hipMemcpyDeviceToHost));
+        c->cam_map_ok = overflow == 0;
     }
-    rc = apse_k_undistort_build_map(&p, c->cam_map, nullptr);
-    if (rc) return fail(c, rc, "camera map launch failed");
     HIPCHK(c, hipDeviceSynchronize());
     c->cam = p;
     c->cam_on = true;

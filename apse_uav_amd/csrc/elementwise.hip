@@ -27,7 +27,7 @@ __device__ __forceinline__ int clip8(int v) {
 template <bool FUSED>
 __device__ __forceinline__ void pil_stage_row(uint8_t* row, const uint8_t* __restrict__ src, int y, int b, int W, size_t src_img_stride,
                                               const UndistortParams& cam, const LabTables* __restrict__ lut,
-                                              const int2* __restrict__ cam_map) {
+                                              const uint32_t* __restrict__ cam_map, unsigned src_bytes) {
     const uint8_t* srow = src + (size_t)b * src_img_stride + (size_t)y * W * 3;
     const int nbytes = W * 3;
     if constexpr (FUSED) {
@@ -41,10 +41,52 @@ __device__ __forceinline__ void pil_stage_row(uint8_t* row, const uint8_t* __res
             __syncthreads();
         }
         const uint8_t* frame = src + (size_t)b * src_img_stride;
-        for (int x = threadIdx.x; x < W; x += blockDim.x) {
-            int c0, c1, c2;
-            undistort_gamma_pixel(cam, frame, &lab_s, x, y, c0, c1, c2, cam_map);
-            row[x * 3 + 0] = (uint8_t)c0; row[x * 3 + 1] = (uint8_t)c1; row[x * 3 + 2] = (uint8_t)c2;
+        if (cam.do_undistort && cam_map) {
+            // Round 4.  The pass was a chain of dependent round trips per pixel (table entry -> four byte gathers of three loads each
+            // -> LDS look-ups), 15 pixels per thread one after the other: ~60 us per block, latency- not bandwidth-bound, and of the
+            // 117 MB it fetched per 4K frame 66 MB were the 8-byte table entries.  Now: 4-byte entries (preproc_pixel.h), the two
+            // 6-byte rows of a pixel's 2x2 footprint as two range-checked 12-byte loads, and FOUR pixels per thread in flight --
+            // 4 table loads, then 8 gathers, then the arithmetic.  Same integers as undistort_gamma_pixel (tests: 0 differing bytes).
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (int)src_bytes, 0x00020000);
+            const int fo = (int)((size_t)b * src_img_stride);
+            const uint32_t* mrow = cam_map + (size_t)y * W;
+            for (int x0 = threadIdx.x; x0 < W; x0 += 4 * blockDim.x) {
+                uint32_t m[4];
+                int off0[4], off1[4], shl[4];
+                pp_u32x3 d0[4], d1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int x = x0 + u * blockDim.x; m[u] = x < W ? mrow[x] : PP_MAP_FAR; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int x = x0 + u * blockDim.x;
+                    off0[u] = off1[u] = 0; shl[u] = 0;
+                    if (m[u] != PP_MAP_FAR) {
+                        const int dx = (int)(int16_t)(m[u] & 0xffffu), dy = (int)(int16_t)(m[u] >> 16);
+                        const int sx = x + (dx >> 5), sy = y + (dy >> 5);
+                        const int sxc = sx < 0 ? 0 : sx;          // sx = -1: the left tap is outside; load from pixel 0 and shift it into the right tap's place
+                        shl[u] = sx < 0 ? 24 : 0;
+                        off0[u] = fo + (sy * W + sxc) * 3;
+                        off1[u] = off0[u] + W * 3;
+                    }
+                    d0[u] = pp_load12(rs, off0[u]);
+                    d1[u] = pp_load12(rs, off1[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int x = x0 + u * blockDim.x;
+                    if (x >= W) break;
+                    int c0, c1, c2;
+                    undistort_from_taps(cam, m[u], x, y, pp_six(d0[u], off0[u]) << shl[u], pp_six(d1[u], off1[u]) << shl[u], c0, c1, c2);
+                    if (cam.do_gamma) lab_gamma_pixel(&lab_s, c0, c1, c2);
+                    row[x * 3 + 0] = (uint8_t)c0; row[x * 3 + 1] = (uint8_t)c1; row[x * 3 + 2] = (uint8_t)c2;
+                }
+            }
+        } else {
+            for (int x = threadIdx.x; x < W; x += blockDim.x) {
+                int c0, c1, c2;
+                undistort_gamma_pixel(cam, frame, &lab_s, x, y, c0, c1, c2);
+                row[x * 3 + 0] = (uint8_t)c0; row[x * 3 + 1] = (uint8_t)c1; row[x * 3 + 2] = (uint8_t)c2;
+            }
         }
     } else
     // W*3 is a multiple of 4 for every supported width (W % 4 == 0); rows start 4-byte aligned.
@@ -65,11 +107,11 @@ __global__ __launch_bounds__(256) void pil_resize_h(const uint8_t* __restrict__ 
                                                     const int* __restrict__ bounds, const int* __restrict__ coef,
                                                     int H, int W, int OW, int ksize, size_t src_img_stride,
                                                     size_t tmp_img_stride, const UndistortParams cam, const LabTables* __restrict__ lut,
-                                                    const int2* __restrict__ cam_map, int tp) {
+                                                    const uint32_t* __restrict__ cam_map, int tp, unsigned src_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint8_t* row = reinterpret_cast<uint8_t*>(smem);
     const int y = blockIdx.x, b = blockIdx.y;
-    pil_stage_row<FUSED>(row, src, y, b, W, src_img_stride, cam, lut, cam_map);
+    pil_stage_row<FUSED>(row, src, y, b, W, src_img_stride, cam, lut, cam_map, src_bytes);
     __syncthreads();
     uint8_t* orow = tmp + (size_t)b * tmp_img_stride + (size_t)y * tp;
     for (int o = threadIdx.x; o < OW * 3; o += blockDim.x) {
@@ -93,19 +135,28 @@ __global__ __launch_bounds__(256) void pil_resize_h8(const uint8_t* __restrict__
                                                      const int2* __restrict__ bounds, const int* __restrict__ coef,
                                                      int H, int W, int OW, int ksize, size_t src_img_stride,
                                                      size_t tmp_img_stride, const UndistortParams cam, const LabTables* __restrict__ lut,
-                                                     const int2* __restrict__ cam_map, const int* __restrict__ coefT, int tp) {
+                                                     const uint32_t* __restrict__ cam_map, const int* __restrict__ coefT, int tp,
+                                                     unsigned src_bytes, int nb) {
     // coefT (optional): the taps tap-major, [8][OW], zero past a pixel's count.  A wave's load of tap j is then 256 consecutive
     // bytes; pixel-major (coef[ox * ksize + j]) it touches 28 cache lines, and with every block (= source row) re-reading the
     // whole table that was what paced this pass (TA cycles: 144 us per 8 frames at 1.4 TB/s).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint8_t* row = reinterpret_cast<uint8_t*>(smem);                      // W*3 bytes (+ 32: tap slots past the row end)
-    const int y = blockIdx.x, b = blockIdx.y;
+    int y = blockIdx.x, b = blockIdx.y;
+    if (nb > 0) {
+        // fused form, 1-D grid: the nb frames of a batch share the camera's remap table.  Blocks are dealt round-robin over the 8
+        // XCDs, so the blocks of one source row are given ids that are equal mod 8 and adjacent in time: a row of the table
+        // (15 KB) is fetched into ONE XCD's L2 once per batch instead of once per frame.
+        const int id = blockIdx.x, grp = id / (8 * nb), r = id - grp * (8 * nb);
+        y = grp * 8 + (r & 7); b = r >> 3;
+        if (y >= H) return;
+    }
     uint8_t* gdst = tmp + (size_t)b * tmp_img_stride + (size_t)y * tp;          // tp: row pitch of the intermediate image (>= OW * 3)
     // the output row sits in LDS at the same offset mod 16 as its destination, so the 16-byte body of the copy-out is
     // aligned on both sides whatever OW is (1333 * 3 bytes per row: rows start at every alignment)
     const int mis = (int)(reinterpret_cast<uintptr_t>(gdst) & 15);
     uint8_t* orow_l = row + (((size_t)W * 3 + 32 + 15) & ~(size_t)15) + mis;    // OW*3 bytes
-    pil_stage_row<FUSED>(row, src, y, b, W, src_img_stride, cam, lut, cam_map);
+    pil_stage_row<FUSED>(row, src, y, b, W, src_img_stride, cam, lut, cam_map, src_bytes);
     if (threadIdx.x < 32) row[W * 3 + threadIdx.x] = 0;
     __syncthreads();
     // (requesting the taps of all of a thread's pixels before the row is staged -- one round trip instead of four -- was tried:
@@ -407,19 +458,22 @@ int apse_k_pil_resize(const uint8_t* src, uint8_t* tmp, void* out, int out_st, u
     const bool h8 = hk <= 8 && (reinterpret_cast<uintptr_t>(hb) & 7) == 0;
     const size_t lds8 = (((size_t)W * 3 + 32 + 15) & ~(size_t)15) + (size_t)OW * 3 + 32;
     const int2* hb2 = reinterpret_cast<const int2*>(hb);
-    const int2* map2 = reinterpret_cast<const int2*>(cam_map);
+    // the compact remap table and the 12-byte gathers need 32-bit byte offsets into the batch of frames
+    const size_t src_total = (size_t)B * H * W * 3;
+    const uint32_t* map2 = src_total < 0x7ffffff0ull ? reinterpret_cast<const uint32_t*>(cam_map) : nullptr;
+    const unsigned sb = (unsigned)(src_total < 0x7ffffff0ull ? src_total : 0);
     if (h8 && fused)
-        hipLaunchKernelGGL(pil_resize_h8<true>, dim3(H, B), dim3(256), lds8, s, src, tmp, hb2, hc, H, W, OW, hk, (size_t)H * W * 3,
-                           (size_t)H * tp, *cam, lut, map2, hcT, tp);
+        hipLaunchKernelGGL(pil_resize_h8<true>, dim3(((H + 7) / 8) * 8 * B), dim3(256), lds8, s, src, tmp, hb2, hc, H, W, OW, hk, (size_t)H * W * 3,
+                           (size_t)H * tp, *cam, lut, map2, hcT, tp, sb, B);
     else if (h8)
         hipLaunchKernelGGL(pil_resize_h8<false>, dim3(H, B), dim3(256), lds8, s, src, tmp, hb2, hc, H, W, OW, hk, (size_t)H * W * 3,
-                           (size_t)H * tp, none, (const LabTables*)nullptr, (const int2*)nullptr, hcT, tp);
+                           (size_t)H * tp, none, (const LabTables*)nullptr, (const uint32_t*)nullptr, hcT, tp, 0u, 0);
     else if (fused)
         hipLaunchKernelGGL(pil_resize_h<true>, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
-                           (size_t)H * W * 3, (size_t)H * tp, *cam, lut, map2, tp);
+                           (size_t)H * W * 3, (size_t)H * tp, *cam, lut, map2, tp, sb);
     else
         hipLaunchKernelGGL(pil_resize_h<false>, dim3(H, B), dim3(256), (size_t)W * 3, s, src, tmp, hb, hc, H, W, OW, hk,
-                           (size_t)H * W * 3, (size_t)H * tp, none, (const LabTables*)nullptr, (const int2*)nullptr, tp);
+                           (size_t)H * W * 3, (size_t)H * tp, none, (const LabTables*)nullptr, (const uint32_t*)nullptr, tp, 0u);
     if ((tp & 3) == 0 && vk <= 8 && (reinterpret_cast<uintptr_t>(tmp) & 3) == 0)
         hipLaunchKernelGGL(pil_resize_v_norm_dw, dim3(((OW * 3 + 3) / 4 + 255) / 256, (OH + PIL_VROWS - 1) / PIL_VROWS, B), dim3(256), 0, s, tmp, out,
                            out_st, vb, vc, OH, OW, vk, PH, PW, mean[0], mean[1], mean[2], (size_t)H * tp, tp, resized_u8);

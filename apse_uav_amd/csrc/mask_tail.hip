@@ -30,6 +30,7 @@ struct PasteParams {
     unsigned long long* sums;   // [n][3] mass, sum(x+1), sum(y+1): zero when the launch starts (pack_detections clears them)
 };
 
+#define MT_TARGETS 100            // detections per image (TEST.DETECTIONS_PER_IMAGE <= 100, apse_create)
 #define MT_MAXDET 1024            // packed detections per forward (apse_create enforces max_batch * dets_per_image <= this)
 #define PASTE_BLOCKS 1024
 // Rows of a window per work item.  The band is picked per launch from the windows' total row count so that there are enough
@@ -235,8 +236,8 @@ __device__ __forceinline__ uint64_t mt_boundary_word(const uint64_t* __restrict_
 
 // closest[i][jl] for every detection i and every target jl of the same image.  Work item = (mask i,
 // band of `cb` window rows, picked like the paste launch's); each thread scans the BOUNDARY pixels of its words (mt_boundary_word:
-// the minimiser is a boundary pixel, or the target itself when it lies on the mask -- tested in the epilogue) once per group of 8
-// targets and keeps 8 running minima of (f32 distance bits, row-major index); block minima are merged with atomicMin on
+// the minimiser is a boundary pixel, or the target itself when it lies on the mask -- tested in the epilogue) against the image's
+// targets, eight running minima of (f32 distance bits, row-major index) at a time, merged per target in LDS; block minima are merged with atomicMin on
 // 64-bit keys (order-independent) IN the record's `closest` field; the host turns a key into 1-based (x, y) when it
 // has the record (apse_read_results_end).  Prologue (every block, one thread per detection): the band prefix and the
 // centroids -- centroid[i] = (floor(sum_x / mass), floor(sum_y / mass)) or (-1, -1) for an empty mask; block 0 writes
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
     __shared__ int band0[MT_MAXDET + 1];
     __shared__ int cent[MT_MAXDET][2];
     __shared__ int rowsv[MT_MAXDET];
-    __shared__ unsigned long long best[4][8];
+    __shared__ unsigned long long best_l[MT_TARGETS];      // running minimum per target of the item's image (LDS atomics)
     __shared__ int wtot[4];
     const int n = *total < n_max ? *total : n_max;
     const int nd = n < MT_MAXDET ? n : MT_MAXDET;
@@ -270,32 +271,44 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
     __syncthreads();
     mt_scan(band0, nd, wtot);
     const int nitems = band0[nd];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int i = mt_find(band0, nd, item);
         const int band = item - band0[i];
-        const int j0 = offset[img[i]], j1 = offset[img[i] + 1];
+        const int j0 = offset[img[i]];
+        int j1 = offset[img[i] + 1];
+        j1 = j1 < nd ? j1 : nd;
+        j1 = j1 - j0 < MT_TARGETS ? j1 : j0 + MT_TARGETS;          // kd <= 100 targets per image (apse_create)
+        const int nt = j1 - j0;
         const int rx0 = rect[i * 4 + 0], ry0 = rect[i * 4 + 1], rx1 = rect[i * 4 + 2], ry1 = rect[i * 4 + 3];
         const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
         const int nw = w1 - w0;
         const int yb = ry0 + band * cb;
         const int nrows = ((yb + cb) < ry1 ? (yb + cb) : ry1) - yb;
         const uint64_t* bits = bits_all + (size_t)i * out_h * words_per_row;
-        for (int jg = j0; jg < j1; jg += 8) {
-            float px[8], py[8];
-            unsigned long long b[8];
+        for (int t = threadIdx.x; t < nt; t += blockDim.x) best_l[t] = ~0ull;
+        __syncthreads();
+        // Each thread takes its words ONCE: the boundary word is extracted (five loads), and for every boundary pixel all targets of
+        // the image are walked eight at a time.  A thread that found a candidate for a target merges it with an LDS atomic; with
+        // boundary pixels only, few threads hold candidates, so this replaces the block-wide reduction (two barriers and 96 lane
+        // exchanges per group of eight targets and item) that dominated once the pixel loop had shrunk (round 4: 491 -> 162 us per
+        // 4 frames at ~38 detections per frame with the reductions, see DESIGN for the figure with the atomics).
+        for (int t = threadIdx.x; t < nw * nrows; t += blockDim.x) {
+            const int ry = t / nw, w = w0 + (t - ry * nw);
+            const int y = yb + ry;
+            const uint64_t bword = mt_boundary_word(bits, y, w, ry0, ry1, w0, w1, words_per_row);
+            if (!bword) continue;
+            for (int jg = 0; jg < nt; jg += 8) {
+                float px[8], py[8];
+                unsigned long long b[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int j = jg + k;
-                const bool ok = j < j1 && j < nd && cent[j < nd ? j : 0][0] >= 0;
-                px[k] = ok ? (float)cent[j][0] : 0.f;
-                py[k] = ok ? (float)cent[j][1] : 0.f;
-                b[k] = ~0ull;
-            }
-            for (int t = threadIdx.x; t < nw * nrows; t += blockDim.x) {
-                const int ry = t / nw, w = w0 + (t - ry * nw);
-                const int y = yb + ry;
-                uint64_t word = mt_boundary_word(bits, y, w, ry0, ry1, w0, w1, words_per_row);
+                for (int k = 0; k < 8; ++k) {
+                    const int j = j0 + jg + k;
+                    const bool ok = jg + k < nt && cent[jg + k < nt ? j : j0][0] >= 0;
+                    px[k] = ok ? (float)cent[j][0] : 0.f;
+                    py[k] = ok ? (float)cent[j][1] : 0.f;
+                    b[k] = ~0ull;
+                }
+                uint64_t word = bword;
                 while (word) {
                     const int bit = __ffsll((long long)word) - 1;
                     word &= word - 1;
@@ -309,31 +322,26 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
                         b[k] = key < b[k] ? key : b[k];
                     }
                 }
-            }
-            __syncthreads();                    // best[] of the previous group has been consumed
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                unsigned long long v = b[k];
-                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(v, o); v = other < v ? other : v; }
-                if (lane == 0) best[wave][k] = v;
-            }
-            __syncthreads();
-            if (threadIdx.x < 8) {
-                const int j = jg + threadIdx.x;
-                if (j < j1 && j < nd && cent[j][0] >= 0) {
-                    unsigned long long v = best[0][threadIdx.x];
-                    for (int q = 1; q < 4; ++q) v = best[q][threadIdx.x] < v ? best[q][threadIdx.x] : v;
-                    // the target itself, when it is a pixel of this mask (possibly an interior one) in this band: distance 0
-                    const int tx = cent[j][0] - 1, ty = cent[j][1] - 1;
-                    if (ty >= yb && ty < yb + nrows && tx >= (w0 << 6) && tx < (w1 << 6) &&
-                        ((bits[(size_t)ty * words_per_row + (tx >> 6)] >> (tx & 63)) & 1ull)) {
-                        const unsigned long long self = (unsigned long long)(unsigned)(ty * out_w + tx);
-                        v = self < v ? self : v;
-                    }
-                    if (v != ~0ull) atomicMin(keys + (size_t)i * kd + (j - j0), v);
-                }
+                for (int k = 0; k < 8; ++k)
+                    if (jg + k < nt && cent[j0 + jg + k][0] >= 0) atomicMin(&best_l[jg + k], b[k]);
             }
         }
+        __syncthreads();
+        for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+            const int j = j0 + t;
+            if (cent[j][0] < 0) continue;
+            unsigned long long v = best_l[t];
+            // the target itself, when it is a pixel of this mask (possibly an interior one) in this band: distance 0
+            const int tx = cent[j][0] - 1, ty = cent[j][1] - 1;
+            if (ty >= yb && ty < yb + nrows && tx >= (w0 << 6) && tx < (w1 << 6) &&
+                ((bits[(size_t)ty * words_per_row + (tx >> 6)] >> (tx & 63)) & 1ull)) {
+                const unsigned long long self = (unsigned long long)(unsigned)(ty * out_w + tx);
+                v = self < v ? self : v;
+            }
+            if (v != ~0ull) atomicMin(keys + (size_t)i * kd + t, v);
+        }
+        __syncthreads();                        // best_l is reset for the next item
     }
 }
 

@@ -20,17 +20,15 @@ __global__ __launch_bounds__(256) void undistort_gamma(const UndistortParams p, 
     o[0] = (uint8_t)c0; o[1] = (uint8_t)c1; o[2] = (uint8_t)c2;
 }
 
-// Built once per camera (apse_set_camera): the remap table of undistort_map_pixel.
-__global__ __launch_bounds__(256) void undistort_build_map(const UndistortParams p, int2* __restrict__ map) {
+// Built once per camera (apse_set_camera): the remap table of the fused path.
+// The compact form (4 bytes per pixel, preproc_pixel.h); *overflow counts pixels inside the frame whose displacement does not fit.
+__global__ __launch_bounds__(256) void undistort_build_map_compact(const UndistortParams p, uint32_t* __restrict__ map, int* __restrict__ overflow) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= p.W) return;
-    int sx, sy, fx, fy;
-    undistort_map_pixel(p, x, y, sx, sy, fx, fy);
-    map[(size_t)y * p.W + x] = int2{sx, (sy << 10) | (fx << 5) | fy};
+    map[(size_t)y * p.W + x] = undistort_map_compact(p, x, y, overflow);
 }
-
-extern "C" int apse_k_undistort_build_map(const UndistortParams* p, void* map, hipStream_t s) {
-    hipLaunchKernelGGL(undistort_build_map, dim3((p->W + 255) / 256, p->H), dim3(256), 0, s, *p, reinterpret_cast<int2*>(map));
+extern "C" int apse_k_undistort_build_map_compact(const UndistortParams* p, void* map, int* overflow_dev, hipStream_t s) {
+    hipLaunchKernelGGL(undistort_build_map_compact, dim3((p->W + 255) / 256, p->H), dim3(256), 0, s, *p, reinterpret_cast<uint32_t*>(map), overflow_dev);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 

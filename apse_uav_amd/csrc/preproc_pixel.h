@@ -106,20 +106,35 @@ __device__ __forceinline__ void undistort_map_pixel(const UndistortParams& p, in
     fx = (int)(iu & 31); fy = (int)(iv & 31);
 }
 
-// s: the frame [H][W][3] u8 (BGR); (x, y): destination pixel; out: its three channels.  map (optional): the camera's remap table
-// [H][W] of (sx, sy << 0 | fractions) built once by apse_set_camera with undistort_map_pixel -- the map depends on the camera
-// only, the f64 rational model per pixel was most of this function's time; lab: the Lab tables (device copy of LabTables).
+// Lab-L gamma of one pixel (channel 0 plays "R": the reference converts a BGR frame with COLOR_RGB2LAB), in place.
+__device__ __forceinline__ void lab_gamma_pixel(const LabTables* __restrict__ lab, int& c0, int& c1, int& c2) {
+    const int R = lab->lin[c0], G = lab->lin[c1], B = lab->lin[c2];
+    const int fX = lab->cbrt[(R * lab->c[0] + G * lab->c[1] + B * lab->c[2] + 2048) >> 12];
+    const int fY = lab->cbrt[(R * lab->c[3] + G * lab->c[4] + B * lab->c[5] + 2048) >> 12];
+    const int fZ = lab->cbrt[(R * lab->c[6] + G * lab->c[7] + B * lab->c[8] + 2048) >> 12];
+    const int L8 = pp_sat8i((296 * fY - 1336934 + 16384) >> 15);           // (116 fY - 16) * 255 / 100 in Q15: 296 = (116 * 255 + 50) / 100, 1336934 = (16 * 255 * 2^15 + 50) / 100
+    const int a8 = pp_sat8i((500 * (fX - fY) + (128 << 15) + 16384) >> 15);
+    const int b8 = pp_sat8i((200 * (fY - fZ) + (128 << 15) + 16384) >> 15);
+    const int L2 = lab->lut[L8];
+    const long long fy = lab->fy[L2];
+    const long long X = pp_lab_finv_q15(fy + lab->at[a8]), Y = lab->y[L2], Z = pp_lab_finv_q15(fy - lab->bt[b8]);
+    long long r = (X * lab->ci[0] + Y * lab->ci[1] + Z * lab->ci[2] + 16384) >> 15;
+    long long g = (X * lab->ci[3] + Y * lab->ci[4] + Z * lab->ci[5] + 16384) >> 15;
+    long long bl = (X * lab->ci[6] + Y * lab->ci[7] + Z * lab->ci[8] + 16384) >> 15;
+    r = r < 0 ? 0 : (r > LAB_INV_N ? LAB_INV_N : r);
+    g = g < 0 ? 0 : (g > LAB_INV_N ? LAB_INV_N : g);
+    bl = bl < 0 ? 0 : (bl > LAB_INV_N ? LAB_INV_N : bl);
+    c0 = lab->inv[r]; c1 = lab->inv[g]; c2 = lab->inv[bl];
+}
+
+// s: the frame [H][W][3] u8 (BGR); (x, y): destination pixel; out: its three channels; lab: the Lab tables (device copy of
+// LabTables).  The f64 rational model is evaluated per pixel: the form of the stand-alone operator, and of a context whose camera
+// does not fit the compact remap table below.
 __device__ __forceinline__ void undistort_gamma_pixel(const UndistortParams& p, const uint8_t* __restrict__ s,
-                                                      const LabTables* __restrict__ lab, int x, int y, int& c0, int& c1, int& c2,
-                                                      const int2* __restrict__ map = nullptr) {
+                                                      const LabTables* __restrict__ lab, int x, int y, int& c0, int& c1, int& c2) {
     if (p.do_undistort) {
         int sx, sy, fx, fy;
-        if (map) {
-            const int2 mv = map[(size_t)y * p.W + x];
-            sx = mv.x; sy = mv.y >> 10; fx = (mv.y >> 5) & 31; fy = mv.y & 31;
-        } else {
-            undistort_map_pixel(p, x, y, sx, sy, fx, fy);
-        }
+        undistort_map_pixel(p, x, y, sx, sy, fx, fy);
         const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
         int acc[3] = {1 << 14, 1 << 14, 1 << 14};
         const bool x0 = (unsigned)sx < (unsigned)p.W, x1 = (unsigned)(sx + 1) < (unsigned)p.W;
@@ -134,25 +149,56 @@ __device__ __forceinline__ void undistort_gamma_pixel(const UndistortParams& p, 
         const uint8_t* q = s + ((size_t)y * p.W + x) * 3;
         c0 = q[0]; c1 = q[1]; c2 = q[2];
     }
-    if (p.do_gamma) {
-        // channel 0 plays "R" (the reference converts a BGR frame with COLOR_RGB2LAB)
-        const int R = lab->lin[c0], G = lab->lin[c1], B = lab->lin[c2];
-        const int fX = lab->cbrt[(R * lab->c[0] + G * lab->c[1] + B * lab->c[2] + 2048) >> 12];
-        const int fY = lab->cbrt[(R * lab->c[3] + G * lab->c[4] + B * lab->c[5] + 2048) >> 12];
-        const int fZ = lab->cbrt[(R * lab->c[6] + G * lab->c[7] + B * lab->c[8] + 2048) >> 12];
-        const int L8 = pp_sat8i((296 * fY - 1336934 + 16384) >> 15);           // (116 fY - 16) * 255 / 100 in Q15: 296 = (116 * 255 + 50) / 100, 1336934 = (16 * 255 * 2^15 + 50) / 100
-        const int a8 = pp_sat8i((500 * (fX - fY) + (128 << 15) + 16384) >> 15);
-        const int b8 = pp_sat8i((200 * (fY - fZ) + (128 << 15) + 16384) >> 15);
-        const int L2 = lab->lut[L8];
-        const long long fy = lab->fy[L2];
-        const long long X = pp_lab_finv_q15(fy + lab->at[a8]), Y = lab->y[L2], Z = pp_lab_finv_q15(fy - lab->bt[b8]);
-        long long r = (X * lab->ci[0] + Y * lab->ci[1] + Z * lab->ci[2] + 16384) >> 15;
-        long long g = (X * lab->ci[3] + Y * lab->ci[4] + Z * lab->ci[5] + 16384) >> 15;
-        long long bl = (X * lab->ci[6] + Y * lab->ci[7] + Z * lab->ci[8] + 16384) >> 15;
-        r = r < 0 ? 0 : (r > LAB_INV_N ? LAB_INV_N : r);
-        g = g < 0 ? 0 : (g > LAB_INV_N ? LAB_INV_N : g);
-        bl = bl < 0 ? 0 : (bl > LAB_INV_N ? LAB_INV_N : bl);
-        c0 = lab->inv[r]; c1 = lab->inv[g]; c2 = lab->inv[bl];
+    if (p.do_gamma) lab_gamma_pixel(lab, c0, c1, c2);
+}
+
+// ---- the fused path of the horizontal resize pass (round 4): compact remap table + wide gathers, four pixels in flight per thread.
+// Compact table entry (4 bytes instead of 8: the table was 66 of the 117 MB the fused pass fetched per 4K frame): the source
+// position RELATIVE to the destination pixel in 1/32 px, dx = iu - 32 x in the low half, dy = iv - 32 y in the high half, int16
+// each (|displacement| < 1024 px); PP_MAP_FAR marks a pixel whose 2x2 footprint lies outside the frame (reads zeros like any
+// border tap) -- and any pixel whose displacement does not fit, which the builder counts: a camera with such pixels INSIDE the
+// frame keeps the per-pixel f64 model (no table), never a wrong tap.
+#define PP_MAP_FAR 0x80008000u
+__device__ __forceinline__ uint32_t undistort_map_compact(const UndistortParams& p, int x, int y, int* overflow) {
+    int sx, sy, fx, fy;
+    undistort_map_pixel(p, x, y, sx, sy, fx, fy);
+    const bool touches = sx >= -1 && sx < p.W && sy >= -1 && sy < p.H;          // some tap of the 2x2 footprint is a frame pixel
+    if (!touches) return PP_MAP_FAR;
+    const int dx = ((sx - x) << 5) | fx, dy = ((sy - y) << 5) | fy;
+    if (dx <= -32768 || dx > 32767 || dy <= -32768 || dy > 32767) { if (overflow) atomicAdd(overflow, 1); return PP_MAP_FAR; }
+    return (uint32_t)(uint16_t)(int16_t)dx | ((uint32_t)(uint16_t)(int16_t)dy << 16);
+}
+// Six consecutive bytes (two BGR pixels) at byte offset `off` of the frames buffer through a range-checked descriptor: three
+// aligned dwords, funnel-shifted (a byte gather is 12 load instructions per pixel; this is 2).  Bytes outside the buffer read 0.
+typedef unsigned int pp_u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ pp_u32x3 pp_load12(__amdgpu_buffer_rsrc_t rs, int off) {
+    return __builtin_amdgcn_raw_buffer_load_b96(rs, off & ~3, 0, 0);
+}
+__device__ __forceinline__ unsigned long long pp_six(pp_u32x3 d, int off) {
+    const int sh = (off & 3) * 8;
+    const unsigned long long lo = ((unsigned long long)d.y << 32) | d.x;
+    return sh ? ((lo >> sh) | ((unsigned long long)d.z << (64 - sh))) : lo;
+}
+// One pixel from its table entry and its two gathered 6-byte rows (row sy: q0, row sy + 1: q1); same integer arithmetic and tap
+// order as undistort_gamma_pixel.
+__device__ __forceinline__ void undistort_from_taps(const UndistortParams& p, uint32_t m, int x, int y, unsigned long long q0,
+                                                    unsigned long long q1, int& c0, int& c1, int& c2) {
+    int sx = -2, sy = -2, fx = 0, fy = 0;
+    if (m != PP_MAP_FAR) {
+        const int dx = (int)(int16_t)(m & 0xffffu), dy = (int)(int16_t)(m >> 16);
+        sx = x + (dx >> 5); sy = y + (dy >> 5); fx = dx & 31; fy = dy & 31;
     }
+    const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    int acc[3] = {1 << 14, 1 << 14, 1 << 14};
+    const bool x0 = (unsigned)sx < (unsigned)p.W, x1 = (unsigned)(sx + 1) < (unsigned)p.W;
+    const bool y0 = (unsigned)sy < (unsigned)p.H, y1 = (unsigned)(sy + 1) < (unsigned)p.H;
+#define PP_B(q, k) ((int)(((q) >> (8 * (k))) & 0xffull))
+    if (y0 && x0) { acc[0] += PP_B(q0, 0) * w00; acc[1] += PP_B(q0, 1) * w00; acc[2] += PP_B(q0, 2) * w00; }
+    if (y0 && x1) { acc[0] += PP_B(q0, 3) * w01; acc[1] += PP_B(q0, 4) * w01; acc[2] += PP_B(q0, 5) * w01; }
+    if (y1 && x0) { acc[0] += PP_B(q1, 0) * w10; acc[1] += PP_B(q1, 1) * w10; acc[2] += PP_B(q1, 2) * w10; }
+    if (y1 && x1) { acc[0] += PP_B(q1, 3) * w11; acc[1] += PP_B(q1, 4) * w11; acc[2] += PP_B(q1, 5) * w11; }
+#undef PP_B
+    c0 = acc[0] >> 15; c1 = acc[1] >> 15; c2 = acc[2] >> 15;
+    c0 = c0 > 255 ? 255 : c0; c1 = c1 > 255 ? 255 : c1; c2 = c2 > 255 ? 255 : c2;
 }
 #endif

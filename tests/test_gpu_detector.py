@@ -480,3 +480,30 @@ def test_fused_preproc_equals_two_kernel_form(setup, golden_dir):
         plain.model.preprocess_frames(plain._upload([frame]))
         assert torch.equal(got[0], got[1])
         assert not torch.equal(got[0], plain.model.debug_tensor("input").cpu())      # the camera model does change the pixels
+    # round 4 (compact remap table, 12-byte gathers, the batch's rows grouped per XCD): a batch of three different frames at the small
+    # size (270 rows: not a multiple of the 8-row groups), and a camera whose distortion moves pixels by more than the table's
+    # +-1023 px at 4K -- it must fall back to the per-pixel model and still give the stand-alone operator's bytes
+    cfg3 = _cfg()
+    cfg3.APSE.MAX_BATCH = 3
+    frames = [SyntheticSequence("dynamic", *FRAME).frame(t) for t in (0, 9, 31)]
+    s = FRAME[1] / 3840.0
+    mtx = np.asarray(cam["mtx"], np.float64)
+    mtx[0] *= s
+    mtx[1] *= s
+    got = []
+    for fused in (True, False):
+        pr = TrackPredictor(cfg3, state_dict=setup["sd"])
+        pr.set_camera(dict(mtx=mtx.tolist(), dist=cam["dist"]), fused=fused)
+        pr.model.preprocess_frames(pr._upload(frames))
+        got.append(pr.model.debug_tensor("input").cpu())
+    assert torch.equal(got[0], got[1]) and not torch.equal(got[0][:got[0].numel() // 3], got[0][got[0].numel() // 3:2 * (got[0].numel() // 3)])
+    from apse_uav_amd.config import setup_cfg
+    wild = dict(mtx=cam["mtx"], dist=[-1.5, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])      # k1 = -1.5: 378 157 pixels come from > 1023 px away, inside the frame
+    frame = SyntheticSequence("dynamic", 2160, 3840).frame(3)
+    got = []
+    for fused in (True, False):
+        pr = TrackPredictor(setup_cfg(), state_dict=setup["sd"])
+        pr.set_camera(wild, fused=fused)
+        pr.model.preprocess_frames(pr._upload([frame]))
+        got.append(pr.model.debug_tensor("input").cpu())
+    assert torch.equal(got[0], got[1])

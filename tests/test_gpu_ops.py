@@ -141,15 +141,23 @@ def test_conv2d_16bit_storage(case, prec, logdir):
     # agree except where that tiny difference straddles a rounding boundary (then by one 16-bit ulp)
     ulp = 2.0 ** (-7 if prec == 1 else -10)        # one unit in the last place, relative to the binade's lower edge
     diff = (out - r16(ref)).abs()
-    tol = ulp * ref.abs().clamp_min(1e-3) * 1.01 + 1e-6
+    # + 4e-6: f32 summation-order noise of a unit-variance sum that cancels to |ref| < 1e-3 [round 4: 7 of 7.1 M outputs of the K = 512
+    # case sit at 2.3e-6 from the reference with |ref| = 6e-4; the LDS-DMA kernel and the tiled kernel agree on them bit for bit]
+    tol = ulp * ref.abs().clamp_min(1e-3) * 1.01 + 4e-6
     frac = float((diff > 1e-6 * ref.abs().clamp_min(1.0)).float().mean())
-    _log(logdir, "conv_16bit_storage/%d/" % prec + name, dict(max=float(diff.max()), frac_differs=frac))
-    assert bool((diff <= tol).all()) and frac < 0.02
+    worst = int(torch.argmax(diff / tol))
+    info = dict(max=float(diff.max()), frac_differs=frac, violations=int((diff > tol).sum()), worst_ratio=float((diff / tol).flatten()[worst]),
+                worst_ref=float(ref.flatten()[worst]), worst_out=float(out.flatten()[worst]))
     if cfg == 11:
         # the LDS-DMA kernel (any of its tiles, ping-pong schedule) runs the MFMA chain of the register-staged tiles: same bits
         tiled = hip_conv2d(x, w, b, stride, pad, relu, res, res_mode, 0, splitk, prec=prec, x_st=prec, res_st=prec if res is not None else 0,
                            y_st=prec)
-        assert torch.equal(out, tiled), name
+        info["equal_to_tiled"] = bool(torch.equal(out, tiled))
+        info["unequal_elems"] = int((out != tiled).sum())
+    _log(logdir, "conv_16bit_storage/%d/" % prec + name, info)
+    if cfg == 11:
+        assert info["equal_to_tiled"], info
+    assert bool((diff <= tol).all()) and frac < 0.02, info
     # f32-compute kernel reading 16-bit activations (decision layers in 16-bit storage mode)
     if cfg in (-1, 2) and res_mode == 0:
         out32 = hip_conv2d(x, w, b, stride, pad, relu, None, 0, cfg, splitk, prec=0, x_st=prec)
