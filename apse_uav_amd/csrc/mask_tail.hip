@@ -45,9 +45,9 @@ struct PasteParams {
 #ifndef PASTE_ITEMS_MIN
 #define PASTE_ITEMS_MIN 3000
 #endif
-#define CP_BAND_MAX 32
+#define CP_BAND_MAX 64
 #ifndef CP_ITEMS_MIN
-#define CP_ITEMS_MIN 512
+#define CP_ITEMS_MIN 384
 #endif
 // largest band in {bmax, bmax/2, .., bmin} that still gives at least `want` items (rows / band is a lower bound of the item count)
 __device__ __forceinline__ int mt_pick_band(int total_rows, int bmax, int bmin, int want) {
@@ -208,40 +208,51 @@ __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_ma
     }
 }
 
-// Boundary pixels of one 64-pixel word of a bit plane: mask pixels with at least one 4-neighbour outside the mask.  Rows outside
-// [ry0, ry1) and words outside [w0, w1) are outside the mask (the paste kernel writes exactly that window; bits of a window
-// word beyond the window's columns are written as zeros).  Bit b of a word is pixel x = 64 w + b.
-//
-// Why the closest point may be searched among these only (round 4; compute_closest_point, dcnn/utils/mask_utils.py:6-23: argmin of
-// the f32 value fl(fl(dx^2) + fl(dy^2)) in row-major order): the targets are integer pixel positions (floor centroids), so dx, dy
-// and their squares (< 2^24) are exact, and d = dx^2 + dy^2 is exact below 2^24 and rounded to a multiple of 2 in [2^24, 2^25).
-// Let P be an INTERIOR mask pixel (all four neighbours in the mask) other than the target, a = max(|dx|, |dy|) >= 1, and P' its
-// neighbour one step toward the target along that axis: d' = d - (2a - 1) exactly.  Below 2^24 both are exact integers, so
-// fl(d') < fl(d).  At d >= 2^24, a >= 2896, the decrease >= 5791 exceeds the rounding step (2) many times over: fl(d') < fl(d) again.
-// So an interior pixel is never the minimiser of (fl(d), row-major index) -- except the target pixel itself when it is a mask pixel
-// (d = 0, the unique smallest key), which the callers test directly.
-__device__ __forceinline__ uint64_t mt_boundary_word(const uint64_t* __restrict__ bits, int y, int w, int ry0, int ry1, int w0, int w1,
-                                                     int words_per_row) {
-    const uint64_t* row = bits + (size_t)y * words_per_row;
-    const uint64_t c = row[w];
-    if (!c) return 0ull;
-    const uint64_t up = y > ry0 ? row[w - words_per_row] : 0ull;
-    const uint64_t dn = y + 1 < ry1 ? row[w + words_per_row] : 0ull;
-    const uint64_t lw = w > w0 ? row[w - 1] : 0ull;
-    const uint64_t rw = w + 1 < w1 ? row[w + 1] : 0ull;
-    const uint64_t left = (c << 1) | (lw >> 63);          // bit b: pixel x - 1 is in the mask
-    const uint64_t right = (c >> 1) | (rw << 63);         // bit b: pixel x + 1 is in the mask
-    return c & ~(left & right & up & dn);
+// Closest mask pixel of ONE 64-pixel word (row y, columns 64 w .. 64 w + 63) to an INTEGER target, in O(1) (round 4).
+// compute_closest_point (dcnn/utils/mask_utils.py:6-23) takes the argmin of the f32 value fl(fl(dx^2) + fl(dy^2)) in row-major
+// order.  Within a row dy is fixed, and for integer targets in a frame of at most 4096 rows fl(d) is STRICTLY increasing in |dx|:
+// dx, dy and their squares (< 2^24) are exact; below 2^24 d is an exact integer; at d >= 2^24 (rounded to a multiple of 2)
+// dy^2 < 2^24 forces |dx| >= 3464, so neighbouring |dx| differ by >= 6929 in d.  The row's minimiser is therefore the set bit with
+// the smallest |dx| -- the nearest set bit at or left of the target column, or the nearest one right of it; at equal |dx| both have
+// the same d and the left one (smaller row-major index) wins, which the (distance bits, index) key order gives for free.  Two
+// candidates per (word, target) instead of one per set bit: the cost no longer depends on how many pixels the mask has (the
+// synthetic weights' masks are speckle: restricting the scan to boundary pixels, tried first, only went from 491 to 162 us per
+// 4 frames at ~38 detections per frame because almost every pixel of such a mask IS a boundary pixel).
+__device__ __forceinline__ unsigned long long mt_word_nearest(uint64_t word, int w, int y, int out_w, float px, float py) {
+    const int r = (int)px - 1 - (w << 6);                 // the target's column relative to the word (may be outside 0..63)
+    const float dy = (float)(y + 1) - py;
+    const float dy2 = dy * dy;
+    const unsigned rowlin = (unsigned)(y * out_w + (w << 6));
+    unsigned long long best = ~0ull;
+    if (r >= 0) {
+        const uint64_t m = r >= 63 ? word : (word & ((2ull << r) - 1ull));          // bits 0 .. r
+        if (m) {
+            const int bpos = 63 - __clzll((long long)m);
+            const float dx = (float)((w << 6) + bpos + 1) - px;
+            best = ((unsigned long long)__float_as_uint(dx * dx + dy2) << 32) | (rowlin + (unsigned)bpos);
+        }
+    }
+    if (r < 63) {
+        const uint64_t m = r < 0 ? word : ((word >> (r + 1)) << (r + 1));            // bits r + 1 .. 63
+        if (m) {
+            const int bpos = __ffsll((long long)m) - 1;
+            const float dx = (float)((w << 6) + bpos + 1) - px;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(dx * dx + dy2) << 32) | (rowlin + (unsigned)bpos);
+            best = key < best ? key : best;
+        }
+    }
+    return best;
 }
 
 // closest[i][jl] for every detection i and every target jl of the same image.  Work item = (mask i,
-// band of `cb` window rows, picked like the paste launch's); each thread scans the BOUNDARY pixels of its words (mt_boundary_word:
-// the minimiser is a boundary pixel, or the target itself when it lies on the mask -- tested in the epilogue) against the image's
-// targets, eight running minima of (f32 distance bits, row-major index) at a time, merged per target in LDS; block minima are merged with atomicMin on
+// band of `cb` window rows, picked like the paste launch's); each thread takes two candidate pixels per word and target
+// (mt_word_nearest) and keeps eight running minima of (f32 distance bits, row-major index) at a time, merged per target in LDS
+// by one atomic per wave; block minima are merged with atomicMin on
 // 64-bit keys (order-independent) IN the record's `closest` field; the host turns a key into 1-based (x, y) when it
 // has the record (apse_read_results_end).  Prologue (every block, one thread per detection): the band prefix and the
 // centroids -- centroid[i] = (floor(sum_x / mass), floor(sum_y / mass)) or (-1, -1) for an empty mask; block 0 writes
 // them to the record.
+template <bool WORDWISE>      // false: frames wider or taller than 4096 pixels (mt_word_nearest's exactness argument needs both bounds): every pixel
 __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict__ bits_all, const int* __restrict__ rect,
                                                       const int* __restrict__ valid, const unsigned long long* __restrict__ sums,
                                                       const int* __restrict__ img, const int* __restrict__ offset,
@@ -287,28 +298,31 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
         const uint64_t* bits = bits_all + (size_t)i * out_h * words_per_row;
         for (int t = threadIdx.x; t < nt; t += blockDim.x) best_l[t] = ~0ull;
         __syncthreads();
-        // Each thread takes its words ONCE: the boundary word is extracted (five loads), and for every boundary pixel all targets of
-        // the image are walked eight at a time.  A thread that found a candidate for a target merges it with an LDS atomic; with
-        // boundary pixels only, few threads hold candidates, so this replaces the block-wide reduction (two barriers and 96 lane
-        // exchanges per group of eight targets and item) that dominated once the pixel loop had shrunk (round 4: 491 -> 162 us per
-        // 4 frames at ~38 detections per frame with the reductions, see DESIGN for the figure with the atomics).
-        for (int t = threadIdx.x; t < nw * nrows; t += blockDim.x) {
-            const int ry = t / nw, w = w0 + (t - ry * nw);
-            const int y = yb + ry;
-            const uint64_t bword = mt_boundary_word(bits, y, w, ry0, ry1, w0, w1, words_per_row);
-            if (!bword) continue;
-            for (int jg = 0; jg < nt; jg += 8) {
-                float px[8], py[8];
-                unsigned long long b[8];
+        // targets eight at a time: a thread walks its words (mt_word_nearest: two candidates per word and target), the wave's
+        // minima are merged by lane exchange and one LDS atomic per wave and target -- no block barrier inside the loop
+        for (int jg = 0; jg < nt; jg += 8) {
+            float px[8], py[8];
+            unsigned long long b[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int j = j0 + jg + k;
-                    const bool ok = jg + k < nt && cent[jg + k < nt ? j : j0][0] >= 0;
-                    px[k] = ok ? (float)cent[j][0] : 0.f;
-                    py[k] = ok ? (float)cent[j][1] : 0.f;
-                    b[k] = ~0ull;
+            for (int k = 0; k < 8; ++k) {
+                const bool ok = jg + k < nt && cent[jg + k < nt ? j0 + jg + k : j0][0] >= 0;
+                px[k] = ok ? (float)cent[j0 + jg + k][0] : 0.f;
+                py[k] = ok ? (float)cent[j0 + jg + k][1] : 0.f;
+                b[k] = ~0ull;
+            }
+            for (int t = threadIdx.x; t < nw * nrows; t += blockDim.x) {
+                const int ry = t / nw, w = w0 + (t - ry * nw);
+                const int y = yb + ry;
+                uint64_t word = bits[(size_t)y * words_per_row + w];
+                if (!word) continue;
+                if (WORDWISE) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const unsigned long long key = mt_word_nearest(word, w, y, out_w, px[k], py[k]);
+                        b[k] = key < b[k] ? key : b[k];
+                    }
+                    continue;
                 }
-                uint64_t word = bword;
                 while (word) {
                     const int bit = __ffsll((long long)word) - 1;
                     word &= word - 1;
@@ -317,29 +331,22 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const float dx = (float)(x + 1) - px[k], dy = (float)(y + 1) - py[k];
-                        const float d = dx * dx + dy * dy;
-                        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | lin;
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(dx * dx + dy * dy) << 32) | lin;
                         b[k] = key < b[k] ? key : b[k];
                     }
                 }
+            }
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (jg + k < nt && cent[j0 + jg + k][0] >= 0) atomicMin(&best_l[jg + k], b[k]);
+            for (int k = 0; k < 8; ++k) {
+                unsigned long long v = b[k];
+                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(v, o); v = other < v ? other : v; }
+                if ((threadIdx.x & 63) == 0 && v != ~0ull && jg + k < nt && cent[j0 + jg + k][0] >= 0) atomicMin(&best_l[jg + k], v);
             }
         }
         __syncthreads();
         for (int t = threadIdx.x; t < nt; t += blockDim.x) {
-            const int j = j0 + t;
-            if (cent[j][0] < 0) continue;
-            unsigned long long v = best_l[t];
-            // the target itself, when it is a pixel of this mask (possibly an interior one) in this band: distance 0
-            const int tx = cent[j][0] - 1, ty = cent[j][1] - 1;
-            if (ty >= yb && ty < yb + nrows && tx >= (w0 << 6) && tx < (w1 << 6) &&
-                ((bits[(size_t)ty * words_per_row + (tx >> 6)] >> (tx & 63)) & 1ull)) {
-                const unsigned long long self = (unsigned long long)(unsigned)(ty * out_w + tx);
-                v = self < v ? self : v;
-            }
-            if (v != ~0ull) atomicMin(keys + (size_t)i * kd + t, v);
+            const unsigned long long v = best_l[t];
+            if (cent[j0 + t][0] >= 0 && v != ~0ull) atomicMin(keys + (size_t)i * kd + t, v);
         }
         __syncthreads();                        // best_l is reset for the next item
     }
@@ -395,22 +402,24 @@ __global__ __launch_bounds__(256) void dense_to_bits(const uint8_t* __restrict__
     if (lane == 0 && mass) { atomicAdd(sums, mass); atomicAdd(sums + 1, sx); atomicAdd(sums + 2, sy); }
 }
 
-// Closest point of ONE packed mask (full-frame rect) to an explicit target (stateless op for mask_utils).  BOUNDARY: the target is
-// an integer pixel position -> the boundary-pixel search of the context's table kernel (same helper); any other target: every pixel.
-template <bool BOUNDARY>
+// Closest point of ONE packed mask (full-frame rect) to an explicit target (stateless op for mask_utils).  WORDWISE: the target is
+// an integer pixel position and the frame has at most 4096 rows -> two candidates per word (mt_word_nearest, the context's table
+// kernel); any other target: every pixel.
+template <bool WORDWISE>
 __global__ __launch_bounds__(256) void closest_point_single(const uint64_t* __restrict__ bits, int out_h, int out_w,
                                                             int words_per_row, float px, float py,
                                                             unsigned long long* __restrict__ best_out) {
     unsigned long long b = ~0ull;
     const int nwords = out_h * words_per_row;
-    if (BOUNDARY && blockIdx.x == 0 && threadIdx.x == 0) {
-        const int tx = (int)px - 1, ty = (int)py - 1;                 // the target itself, when it is a mask pixel: distance 0
-        if (tx >= 0 && tx < out_w && ty >= 0 && ty < out_h && ((bits[(size_t)ty * words_per_row + (tx >> 6)] >> (tx & 63)) & 1ull))
-            b = (unsigned long long)(unsigned)(ty * out_w + tx);
-    }
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nwords; t += gridDim.x * blockDim.x) {
         const int y = t / words_per_row, w = t - y * words_per_row;
-        uint64_t word = BOUNDARY ? mt_boundary_word(bits, y, w, 0, out_h, 0, words_per_row, words_per_row) : bits[t];
+        uint64_t word = bits[t];
+        if (!word) continue;
+        if (WORDWISE) {
+            const unsigned long long key = mt_word_nearest(word, w, y, out_w, px, py);
+            b = key < b ? key : b;
+            continue;
+        }
         const float dy = (float)(y + 1) - py;
         const float dy2 = dy * dy;
         while (word) {
@@ -431,7 +440,7 @@ extern "C" {
 int apse_k_closest_single(const uint64_t* bits, int out_h, int out_w, int words_per_row, float px, float py,
                           unsigned long long* best_out, hipStream_t s) {
     hipMemsetAsync(best_out, 0xff, sizeof(unsigned long long), s);
-    const bool integral = px == floorf(px) && py == floorf(py) && fabsf(px) < 16777216.f && fabsf(py) < 16777216.f;
+    const bool integral = px == floorf(px) && py == floorf(py) && fabsf(px) < 1048576.f && fabsf(py) < 1048576.f && out_h <= 4096 && out_w <= 4096;
     if (integral) hipLaunchKernelGGL(closest_point_single<true>, dim3(512), dim3(256), 0, s, bits, out_h, out_w, words_per_row, px, py, best_out);
     else hipLaunchKernelGGL(closest_point_single<false>, dim3(512), dim3(256), 0, s, bits, out_h, out_w, words_per_row, px, py, best_out);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
@@ -446,8 +455,12 @@ int apse_k_closest_points(const uint64_t* bits, const int* rect, const int* vali
                           const int* offset, const int* total, int n_max, int kd, int out_h, int out_w, int words_per_row,
                           int* cent, int* mass, unsigned long long* keys, hipStream_t s) {
     if (n_max <= 0) return APSE_OK;
-    hipLaunchKernelGGL(closest_points, dim3(1024), dim3(256), 0, s, bits, rect, valid, sums, img, offset, total, n_max, kd, out_h,
-                       out_w, words_per_row, keys, cent, mass);
+    if (out_h <= 4096 && out_w <= 4096)
+        hipLaunchKernelGGL(closest_points<true>, dim3(1024), dim3(256), 0, s, bits, rect, valid, sums, img, offset, total, n_max, kd, out_h,
+                           out_w, words_per_row, keys, cent, mass);
+    else
+        hipLaunchKernelGGL(closest_points<false>, dim3(1024), dim3(256), 0, s, bits, rect, valid, sums, img, offset, total, n_max, kd, out_h,
+                           out_w, words_per_row, keys, cent, mass);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_copy_mask_windows(const uint64_t* bits, uint64_t* out, int n, const long long* src, const long long* dst, const int* nw,

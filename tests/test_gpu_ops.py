@@ -533,14 +533,14 @@ def test_mask_utils_golden(golden_dir, logdir):
                 assert cen[axis] == c["centroid"][axis], c["name"]
 
 
-def test_closest_point_boundary_search_equals_full_scan(logdir):
-    """Round 4: the closest-point kernels look at BOUNDARY pixels only (mask pixels with a 4-neighbour outside the mask; the target
-    pixel itself is tested directly) -- csrc/mask_tail.hip mt_boundary_word carries the argument why the minimiser of
-    (f32 distance, row-major index) is among them for integer targets.  Random masks -- blobs, blobs with holes, 30 % speckle (nearly
-    every pixel is boundary), word-aligned edges, masks touching the frame border -- and integer targets outside the mask, on
-    interior pixels, on boundary pixels, inside holes, and > 4096 px away (f32 distances above 2^24: rounding ties) against the
-    oracle's full row-major argmin (compute_closest_point restated, dcnn/utils/mask_utils.py:6-23); one non-integer target takes the
-    full-scan kernel."""
+def test_closest_point_word_search_equals_full_scan(logdir):
+    """Round 4: for integer targets the closest-point kernels take TWO candidates per 64-pixel word -- the nearest set bit at or left of
+    the target column and the nearest one right of it (csrc/mask_tail.hip mt_word_nearest carries the argument why the row's minimiser
+    of (f32 distance, row-major index) is one of them in frames up to 4096 x 4096).  Random masks -- blobs, blobs with holes, 30 %
+    speckle, word-aligned edges, masks touching the frame border -- and integer targets outside the mask, on interior pixels, on
+    boundary pixels, inside holes, and > 4096 px away (f32 distances above 2^24: rounding ties) against the oracle's full row-major
+    argmin (compute_closest_point restated, dcnn/utils/mask_utils.py:6-23); one non-integer target takes the every-pixel kernel.
+    The context's table kernel (same helper) is held to the oracle by the detector / full-size tests."""
     from apse_uav_amd.utils import mask_utils
     from oracle import mask_utils as omu
     H, W = 2160, 3840
@@ -582,7 +582,7 @@ def test_closest_point_boundary_search_equals_full_scan(logdir):
             ref = omu.window_closest_point(win, rect, t)
             assert got == ref, (case, t, got, ref)
             checked += 1
-    _log(logdir, "closest_boundary_vs_full", dict(cases=6, targets=checked))
+    _log(logdir, "closest_wordwise_vs_full", dict(cases=6, targets=checked))
 
 
 def test_association_head_golden(golden_dir, logdir):
