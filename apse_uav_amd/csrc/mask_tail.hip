@@ -45,9 +45,9 @@ struct PasteParams {
 #ifndef PASTE_ITEMS_MIN
 #define PASTE_ITEMS_MIN 3000
 #endif
-#define CP_BAND_MAX 64
+#define CP_BAND_MAX 32
 #ifndef CP_ITEMS_MIN
-#define CP_ITEMS_MIN 384
+#define CP_ITEMS_MIN 2048
 #endif
 // largest band in {bmax, bmax/2, .., bmin} that still gives at least `want` items (rows / band is a lower bound of the item count)
 __device__ __forceinline__ int mt_pick_band(int total_rows, int bmax, int bmin, int want) {
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
     }
     __syncthreads();
     mt_scan(band0, nd, wtot);
-    const int cb = mt_pick_band(band0[nd], CP_BAND_MAX, 8, CP_ITEMS_MIN);
+    const int cb = mt_pick_band(band0[nd], CP_BAND_MAX, 4, CP_ITEMS_MIN);
     __syncthreads();
     for (int i = threadIdx.x; i < nd; i += blockDim.x) band0[i] = (rowsv[i] + cb - 1) / cb;
     __syncthreads();

@@ -78,10 +78,16 @@ struct UndistortParams {
 #ifdef __HIPCC__
 __device__ __forceinline__ int pp_sat8i(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 // inverse of f() on a Q15 argument (may be negative): t > 0.206893 ? t^3 : (t - 16 / 116) / 7.787, Q15 result, floor rounding
-// of the shifted products like numpy's >> on int64
-__device__ __forceinline__ long long pp_lab_finv_q15(long long t) {
-    if (t >= 6780) return (t * t * t + (1ll << 29)) >> 30;
-    return ((t - 4520) * 269314 + (1ll << 20)) >> 21;          // 2^21 / 7.787 = 269 314.5; 16 / 116 in Q15 = 4519.7
+// of the shifted products like numpy's >> on int64.  Ranges (from the tables: fy <= 32768, |at| <= 8323, |bt| <= 20972): t in
+// [-20972, 53740], so t^2 < 2^32 and the 32 x 32 -> 64-bit multiply-adds below are exact; the result is in [-3274, 144500].
+// (Round 4: the same integers as the long long form of round 3 -- which made every product a 64 x 64-bit multiply, ~270 VALU
+// instructions per pixel and the fused resize pass VALU-bound -- checked on all 2^24 colours by tests/test_gpu_ops.py.)
+__device__ __forceinline__ int pp_lab_finv_q15(int t) {
+    if (t >= 6780) {
+        const unsigned t2 = (unsigned)t * (unsigned)t;
+        return (int)(((unsigned long long)t2 * (unsigned)t + (1ull << 29)) >> 30);
+    }
+    return (int)(((long long)(t - 4520) * 269314 + (1ll << 20)) >> 21);          // 2^21 / 7.787 = 269 314.5; 16 / 116 in Q15 = 4519.7
 }
 
 // Source position of destination pixel (x, y) in 1/32 px: (sx, sy) integer part, (fx, fy) 5-bit fraction.
@@ -116,11 +122,12 @@ __device__ __forceinline__ void lab_gamma_pixel(const LabTables* __restrict__ la
     const int a8 = pp_sat8i((500 * (fX - fY) + (128 << 15) + 16384) >> 15);
     const int b8 = pp_sat8i((200 * (fY - fZ) + (128 << 15) + 16384) >> 15);
     const int L2 = lab->lut[L8];
-    const long long fy = lab->fy[L2];
-    const long long X = pp_lab_finv_q15(fy + lab->at[a8]), Y = lab->y[L2], Z = pp_lab_finv_q15(fy - lab->bt[b8]);
-    long long r = (X * lab->ci[0] + Y * lab->ci[1] + Z * lab->ci[2] + 16384) >> 15;
-    long long g = (X * lab->ci[3] + Y * lab->ci[4] + Z * lab->ci[5] + 16384) >> 15;
-    long long bl = (X * lab->ci[6] + Y * lab->ci[7] + Z * lab->ci[8] + 16384) >> 15;
+    const int fy = lab->fy[L2];
+    const int X = pp_lab_finv_q15(fy + lab->at[a8]), Y = lab->y[L2], Z = pp_lab_finv_q15(fy - lab->bt[b8]);
+    // |X|, |Z| <= 144500, Y <= 32768, |ci| <= 12615: each product fits 31 bits, the sum of three needs 64 (one v_mad_i64_i32 each)
+    int r = (int)(((long long)X * lab->ci[0] + (long long)Y * lab->ci[1] + (long long)Z * lab->ci[2] + 16384) >> 15);
+    int g = (int)(((long long)X * lab->ci[3] + (long long)Y * lab->ci[4] + (long long)Z * lab->ci[5] + 16384) >> 15);
+    int bl = (int)(((long long)X * lab->ci[6] + (long long)Y * lab->ci[7] + (long long)Z * lab->ci[8] + 16384) >> 15);
     r = r < 0 ? 0 : (r > LAB_INV_N ? LAB_INV_N : r);
     g = g < 0 ? 0 : (g > LAB_INV_N ? LAB_INV_N : g);
     bl = bl < 0 ? 0 : (bl > LAB_INV_N ? LAB_INV_N : bl);
