@@ -58,7 +58,7 @@ int apse_k_l2_normalize(const float*, float*, int, const int*, int, hipStream_t)
 int apse_k_sqdist(const float*, const float*, int, int, int, float*, hipStream_t);
 int apse_k_mask_paste(const PasteParams*, int, unsigned long long*, int, hipStream_t);
 int apse_k_closest_points(const uint64_t*, const int*, const int*, const unsigned long long*, const int*, const int*, const int*, int,
-                          int, int, int, int, int*, int*, unsigned long long*, hipStream_t);
+                          int, int, int, int, int*, int*, unsigned long long*, int, hipStream_t);
 int apse_k_closest_single(const uint64_t*, int, int, int, float, float, unsigned long long*, hipStream_t);
 int apse_k_undistort_gamma(const UndistortParams*, const uint8_t*, uint8_t*, const LabTables*, int, hipStream_t);
 int apse_k_bits_to_dense(const uint64_t*, const int*, int, int, int, uint8_t*, hipStream_t);
@@ -1052,7 +1052,7 @@ int apse_mask_tail(apse_ctx* c, int batch, void* stream) {
     if (rc) return fail(c, rc, "mask paste launch failed");
     rc = apse_k_closest_points(bits, p.rect, p.valid, c->sums, (int*)(r + c->lay.img), (int*)(r + c->lay.offset), total, NM,
                                g.dets_per_image, g.frame_h, g.frame_w, c->wpr, (int*)(r + c->lay.centroid), (int*)(r + c->lay.mass),
-                               keys, s);
+                               keys, c->hint_total, s);
     return rc ? fail(c, rc, "closest points launch failed") : APSE_OK;
 }
 

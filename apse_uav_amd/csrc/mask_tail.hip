@@ -45,10 +45,6 @@ struct PasteParams {
 #ifndef PASTE_ITEMS_MIN
 #define PASTE_ITEMS_MIN 3000
 #endif
-#define CP_BAND_MAX 32
-#ifndef CP_ITEMS_MIN
-#define CP_ITEMS_MIN 2048
-#endif
 // largest band in {bmax, bmax/2, .., bmin} that still gives at least `want` items (rows / band is a lower bound of the item count)
 __device__ __forceinline__ int mt_pick_band(int total_rows, int bmax, int bmin, int want) {
     int b = bmax;
@@ -132,7 +128,12 @@ __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_ma
     mt_scan(band0, nd, wtot);
     const int nitems = band0[nd];
     int cur = -1;
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    // a block takes a CONTIGUOUS range of items: consecutive items are bands of the same detection, so its 28 x 28 sigmoid tile is
+    // built once per block and detection (a grid-strided walk rebuilt it -- 784 strided loads + expf behind a barrier -- for almost
+    // every item: round 4, SQ counters: 56 % of the wave time parked)
+    const int per_block = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int item_end = ((int)blockIdx.x + 1) * per_block < nitems ? ((int)blockIdx.x + 1) * per_block : nitems;
+    for (int item = blockIdx.x * per_block; item < item_end; ++item) {
         const int i = mt_find(band0, nd, item);
         const int band = item - band0[i];
         const int M = p.M;
@@ -244,14 +245,18 @@ __device__ __forceinline__ unsigned long long mt_word_nearest(uint64_t word, int
     return best;
 }
 
-// closest[i][jl] for every detection i and every target jl of the same image.  Work item = (mask i,
-// band of `cb` window rows, picked like the paste launch's); each thread takes two candidate pixels per word and target
-// (mt_word_nearest) and keeps eight running minima of (f32 distance bits, row-major index) at a time, merged per target in LDS
-// by one atomic per wave; block minima are merged with atomicMin on
-// 64-bit keys (order-independent) IN the record's `closest` field; the host turns a key into 1-based (x, y) when it
-// has the record (apse_read_results_end).  Prologue (every block, one thread per detection): the band prefix and the
-// centroids -- centroid[i] = (floor(sum_x / mass), floor(sum_y / mass)) or (-1, -1) for an empty mask; block 0 writes
-// them to the record.
+// closest[i][jl] for every detection i and every target jl of the same image (jl = index of the target among the image's
+// detections).  Round 4 decomposition: a block = (mask i, one of up to CP_PARTS row ranges of its window); its four waves share
+// nothing but the centroids of the image's detections (recomputed per block: <= 100 divisions).  A wave takes target groups of
+// eight (images with fewer than three groups: the waves split the block's rows instead), walks its words 64 at a time with two
+// candidates per word and target (mt_word_nearest), reduces its eight minima by lane exchange and merges them with one global
+// atomicMin per target on the 64-bit (f32 distance bits, row-major index) keys IN the record's `closest` field; the host turns a
+// key into 1-based (x, y) when it has the record (apse_read_results_end).  No scans, no item search, no block barrier in the loop
+// (the item-list form with block-wide reductions: 129 us per 4 frames at ~38 detections per frame, waves per SIMD 1.4, 53 % of the
+// wave time parked).  Block (i, 0) writes detection i's centroid -- (floor(sum_x / mass), floor(sum_y / mass)) or (-1, -1) for an
+// empty mask -- and mass to the record.
+#define CP_PARTS 16               // row ranges per mask (grid x)
+#define CP_ROWS_MIN 16            // rows per range before a mask is cut further
 template <bool WORDWISE>      // false: frames wider or taller than 4096 pixels (mt_word_nearest's exactness argument needs both bounds): every pixel
 __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict__ bits_all, const int* __restrict__ rect,
                                                       const int* __restrict__ valid, const unsigned long long* __restrict__ sums,
@@ -259,96 +264,93 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
                                                       const int* __restrict__ total, int n_max, int kd, int out_h, int out_w,
                                                       int words_per_row, unsigned long long* __restrict__ keys,
                                                       int* __restrict__ cent_out, int* __restrict__ mass_out) {
-    __shared__ int band0[MT_MAXDET + 1];
-    __shared__ int cent[MT_MAXDET][2];
-    __shared__ int rowsv[MT_MAXDET];
-    __shared__ unsigned long long best_l[MT_TARGETS];      // running minimum per target of the item's image (LDS atomics)
-    __shared__ int wtot[4];
+    __shared__ int cent[MT_TARGETS][2];
     const int n = *total < n_max ? *total : n_max;
-    const int nd = n < MT_MAXDET ? n : MT_MAXDET;
-    for (int i = threadIdx.x; i < nd; i += blockDim.x) {
-        const int rows = valid[i] ? rect[i * 4 + 3] - rect[i * 4 + 1] : 0;
-        band0[i] = rowsv[i] = rows;
-        const unsigned long long m = sums[i * 3], sx = sums[i * 3 + 1], sy = sums[i * 3 + 2];
-        const int cx = m ? (int)(sx / m) : -1, cy = m ? (int)(sy / m) : -1;
-        cent[i][0] = cx; cent[i][1] = cy;
-        if (blockIdx.x == 0) { mass_out[i] = (int)m; cent_out[i * 2] = cx; cent_out[i * 2 + 1] = cy; }
-    }
-    __syncthreads();
-    mt_scan(band0, nd, wtot);
-    const int cb = mt_pick_band(band0[nd], CP_BAND_MAX, 4, CP_ITEMS_MIN);
-    __syncthreads();
-    for (int i = threadIdx.x; i < nd; i += blockDim.x) band0[i] = (rowsv[i] + cb - 1) / cb;
-    __syncthreads();
-    mt_scan(band0, nd, wtot);
-    const int nitems = band0[nd];
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const int i = mt_find(band0, nd, item);
-        const int band = item - band0[i];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = blockIdx.y; i < n; i += gridDim.y) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const unsigned long long m = sums[i * 3], sx = sums[i * 3 + 1], sy = sums[i * 3 + 2];
+            mass_out[i] = (int)m;
+            cent_out[i * 2] = m ? (int)(sx / m) : -1;
+            cent_out[i * 2 + 1] = m ? (int)(sy / m) : -1;
+        }
+        const int rx0 = rect[i * 4 + 0], ry0 = rect[i * 4 + 1], rx1 = rect[i * 4 + 2], ry1 = rect[i * 4 + 3];
+        const int rows = valid[i] ? ry1 - ry0 : 0;
+        int P = (rows + CP_ROWS_MIN - 1) / CP_ROWS_MIN;
+        P = P < 1 ? 1 : (P > (int)gridDim.x ? (int)gridDim.x : P);
+        if (rows <= 0 || (int)blockIdx.x >= P) continue;            // block-uniform
         const int j0 = offset[img[i]];
         int j1 = offset[img[i] + 1];
-        j1 = j1 < nd ? j1 : nd;
-        j1 = j1 - j0 < MT_TARGETS ? j1 : j0 + MT_TARGETS;          // kd <= 100 targets per image (apse_create)
-        const int nt = j1 - j0;
-        const int rx0 = rect[i * 4 + 0], ry0 = rect[i * 4 + 1], rx1 = rect[i * 4 + 2], ry1 = rect[i * 4 + 3];
-        const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
-        const int nw = w1 - w0;
-        const int yb = ry0 + band * cb;
-        const int nrows = ((yb + cb) < ry1 ? (yb + cb) : ry1) - yb;
-        const uint64_t* bits = bits_all + (size_t)i * out_h * words_per_row;
-        for (int t = threadIdx.x; t < nt; t += blockDim.x) best_l[t] = ~0ull;
+        j1 = j1 < n ? j1 : n;
+        const int nt = j1 - j0 < MT_TARGETS ? j1 - j0 : MT_TARGETS;   // kd <= 100 targets per image (apse_create)
+        __syncthreads();                                            // the previous mask's centroids are no longer read
+        for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+            const unsigned long long m = sums[(j0 + t) * 3], sx = sums[(j0 + t) * 3 + 1], sy = sums[(j0 + t) * 3 + 2];
+            cent[t][0] = m ? (int)(sx / m) : -1;
+            cent[t][1] = m ? (int)(sy / m) : -1;
+        }
         __syncthreads();
-        // targets eight at a time: a thread walks its words (mt_word_nearest: two candidates per word and target), the wave's
-        // minima are merged by lane exchange and one LDS atomic per wave and target -- no block barrier inside the loop
-        for (int jg = 0; jg < nt; jg += 8) {
+        const int rpp = (rows + P - 1) / P;
+        const int pb = ry0 + (int)blockIdx.x * rpp;
+        const int pe = pb + rpp < ry1 ? pb + rpp : ry1;
+        const int w0 = rx0 >> 6, nw = ((rx1 + 63) >> 6) - w0;
+        const int ngroups = (nt + 7) >> 3;
+        // few target groups: the four waves split the rows of the range instead of the groups
+        const int wsplit = ngroups >= 3 ? 1 : (ngroups == 2 ? 2 : 4);
+        const int sub = wave % wsplit;
+        const int srows = (pe - pb + wsplit - 1) / wsplit;
+        const int yb = pb + sub * srows;
+        const int nrows = (yb + srows < pe ? yb + srows : pe) - yb;
+        if (nrows <= 0) continue;                                   // wave-uniform; no barrier before the loop top's (every wave reaches it)
+        const uint64_t* bits = bits_all + (size_t)i * out_h * words_per_row;
+        for (int jg = (wave / wsplit) * 8; jg < nt; jg += (4 / wsplit) * 8) {
             float px[8], py[8];
             unsigned long long b[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const bool ok = jg + k < nt && cent[jg + k < nt ? j0 + jg + k : j0][0] >= 0;
-                px[k] = ok ? (float)cent[j0 + jg + k][0] : 0.f;
-                py[k] = ok ? (float)cent[j0 + jg + k][1] : 0.f;
+                const bool ok = jg + k < nt && cent[jg + k < nt ? jg + k : 0][0] >= 0;
+                px[k] = ok ? (float)cent[jg + k][0] : 0.f;
+                py[k] = ok ? (float)cent[jg + k][1] : 0.f;
                 b[k] = ~0ull;
             }
-            for (int t = threadIdx.x; t < nw * nrows; t += blockDim.x) {
-                const int ry = t / nw, w = w0 + (t - ry * nw);
-                const int y = yb + ry;
+            int ry = lane / nw, wx = lane - ry * nw;                  // word `lane` of the range, advanced by 64 words per step
+            const int dry = 64 / nw, dwx = 64 - dry * nw;
+            for (; ry < nrows; ) {
+                const int y = yb + ry, w = w0 + wx;
                 uint64_t word = bits[(size_t)y * words_per_row + w];
-                if (!word) continue;
-                if (WORDWISE) {
+                if (word) {
+                    if (WORDWISE) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const unsigned long long key = mt_word_nearest(word, w, y, out_w, px[k], py[k]);
-                        b[k] = key < b[k] ? key : b[k];
-                    }
-                    continue;
-                }
-                while (word) {
-                    const int bit = __ffsll((long long)word) - 1;
-                    word &= word - 1;
-                    const int x = (w << 6) + bit;
-                    const unsigned lin = (unsigned)(y * out_w + x);
+                        for (int k = 0; k < 8; ++k) {
+                            const unsigned long long key = mt_word_nearest(word, w, y, out_w, px[k], py[k]);
+                            b[k] = key < b[k] ? key : b[k];
+                        }
+                    } else {
+                        while (word) {
+                            const int bit = __ffsll((long long)word) - 1;
+                            word &= word - 1;
+                            const int x = (w << 6) + bit;
+                            const unsigned lin = (unsigned)(y * out_w + x);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float dx = (float)(x + 1) - px[k], dy = (float)(y + 1) - py[k];
-                        const unsigned long long key = ((unsigned long long)__float_as_uint(dx * dx + dy * dy) << 32) | lin;
-                        b[k] = key < b[k] ? key : b[k];
+                            for (int k = 0; k < 8; ++k) {
+                                const float dx = (float)(x + 1) - px[k], dy = (float)(y + 1) - py[k];
+                                const unsigned long long key = ((unsigned long long)__float_as_uint(dx * dx + dy * dy) << 32) | lin;
+                                b[k] = key < b[k] ? key : b[k];
+                            }
+                        }
                     }
                 }
+                ry += dry; wx += dwx;
+                if (wx >= nw) { wx -= nw; ++ry; }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 unsigned long long v = b[k];
                 for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(v, o); v = other < v ? other : v; }
-                if ((threadIdx.x & 63) == 0 && v != ~0ull && jg + k < nt && cent[j0 + jg + k][0] >= 0) atomicMin(&best_l[jg + k], v);
+                if (lane == 0 && v != ~0ull && jg + k < nt && cent[jg + k][0] >= 0) atomicMin(keys + (size_t)i * kd + jg + k, v);
             }
         }
-        __syncthreads();
-        for (int t = threadIdx.x; t < nt; t += blockDim.x) {
-            const unsigned long long v = best_l[t];
-            if (cent[j0 + t][0] >= 0 && v != ~0ull) atomicMin(keys + (size_t)i * kd + t, v);
-        }
-        __syncthreads();                        // best_l is reset for the next item
     }
 }
 
@@ -453,13 +455,17 @@ int apse_k_mask_paste(const PasteParams* p, int n_max, unsigned long long* keys,
 }
 int apse_k_closest_points(const uint64_t* bits, const int* rect, const int* valid, const unsigned long long* sums, const int* img,
                           const int* offset, const int* total, int n_max, int kd, int out_h, int out_w, int words_per_row,
-                          int* cent, int* mass, unsigned long long* keys, hipStream_t s) {
+                          int* cent, int* mass, unsigned long long* keys, int hint, hipStream_t s) {
     if (n_max <= 0) return APSE_OK;
+    // grid: CP_PARTS row ranges x masks; the masks dimension is sized from the caller's hint of the live count (any count is handled:
+    // the blocks stride over the masks)
+    int gy = hint > 0 ? 2 * hint : 16;
+    gy = gy < 16 ? 16 : (gy > n_max ? n_max : gy);
     if (out_h <= 4096 && out_w <= 4096)
-        hipLaunchKernelGGL(closest_points<true>, dim3(1024), dim3(256), 0, s, bits, rect, valid, sums, img, offset, total, n_max, kd, out_h,
+        hipLaunchKernelGGL(closest_points<true>, dim3(CP_PARTS, gy), dim3(256), 0, s, bits, rect, valid, sums, img, offset, total, n_max, kd, out_h,
                            out_w, words_per_row, keys, cent, mass);
     else
-        hipLaunchKernelGGL(closest_points<false>, dim3(1024), dim3(256), 0, s, bits, rect, valid, sums, img, offset, total, n_max, kd, out_h,
+        hipLaunchKernelGGL(closest_points<false>, dim3(CP_PARTS, gy), dim3(256), 0, s, bits, rect, valid, sums, img, offset, total, n_max, kd, out_h,
                            out_w, words_per_row, keys, cent, mass);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
