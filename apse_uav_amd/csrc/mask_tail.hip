@@ -128,12 +128,7 @@ __global__ __launch_bounds__(256) void paste_masks(const PasteParams p, int n_ma
     mt_scan(band0, nd, wtot);
     const int nitems = band0[nd];
     int cur = -1;
-    // a block takes a CONTIGUOUS range of items: consecutive items are bands of the same detection, so its 28 x 28 sigmoid tile is
-    // built once per block and detection (a grid-strided walk rebuilt it -- 784 strided loads + expf behind a barrier -- for almost
-    // every item: round 4, SQ counters: 56 % of the wave time parked)
-    const int per_block = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int item_end = ((int)blockIdx.x + 1) * per_block < nitems ? ((int)blockIdx.x + 1) * per_block : nitems;
-    for (int item = blockIdx.x * per_block; item < item_end; ++item) {
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int i = mt_find(band0, nd, item);
         const int band = item - band0[i];
         const int M = p.M;
@@ -246,18 +241,29 @@ __device__ __forceinline__ unsigned long long mt_word_nearest(uint64_t word, int
 }
 
 // closest[i][jl] for every detection i and every target jl of the same image (jl = index of the target among the image's
-// detections).  Round 4 decomposition: a block = (mask i, one of up to CP_PARTS row ranges of its window); its four waves share
-// nothing but the centroids of the image's detections (recomputed per block: <= 100 divisions).  A wave takes target groups of
-// eight (images with fewer than three groups: the waves split the block's rows instead), walks its words 64 at a time with two
-// candidates per word and target (mt_word_nearest), reduces its eight minima by lane exchange and merges them with one global
-// atomicMin per target on the 64-bit (f32 distance bits, row-major index) keys IN the record's `closest` field; the host turns a
-// key into 1-based (x, y) when it has the record (apse_read_results_end).  No scans, no item search, no block barrier in the loop
-// (the item-list form with block-wide reductions: 129 us per 4 frames at ~38 detections per frame, waves per SIMD 1.4, 53 % of the
-// wave time parked).  Block (i, 0) writes detection i's centroid -- (floor(sum_x / mass), floor(sum_y / mass)) or (-1, -1) for an
-// empty mask -- and mass to the record.
+// detections).  Round 4 decomposition: a block = (mask i, one of up to CP_PARTS row ranges of its window).
+//   * Per ROW, not per word: a row's minimiser for a target at column c is its nearest set bit on either side of c (the argument of
+//     mt_word_nearest applies to the whole row).  The block first records every row's first and last set bit (one pass over the
+//     words, shared by all targets); then for a (row, target) pair: c at or left of the first bit -> the first bit; at or right of
+//     the last -> the last; inside the span -> the word under c gives the nearest bit on each side, and only when that word has
+//     none on a side are neighbouring words walked (dense masks: never; a solid blob with a hole under c: a few words).  The work
+//     is rows x targets instead of words x targets (8-30 x fewer pairs on 500-2000 px wide windows): the word form ran 124-129 us
+//     per 4 frames at ~38 detections per frame whatever its decomposition (item list with block reductions, or wave tasks) --
+//     28 M VALU wave-instructions, compute-bound.
+//   * A wave takes target groups of eight (images with fewer than three groups: the waves split the range's rows instead), one row
+//     per lane, reduces its eight minima by lane exchange and merges them with one global atomicMin per target on the 64-bit
+//     (f32 distance bits, row-major index) keys IN the record's `closest` field; the host turns a key into 1-based (x, y) when it has
+//     the record (apse_read_results_end).  No scans, no item search, no block barrier in the loop.
+// Block (i, 0) writes detection i's centroid -- (floor(sum_x / mass), floor(sum_y / mass)) or (-1, -1) for an empty mask -- and
+// mass to the record.
 #define CP_PARTS 16               // row ranges per mask (grid x)
 #define CP_ROWS_MIN 16            // rows per range before a mask is cut further
-template <bool WORDWISE>      // false: frames wider or taller than 4096 pixels (mt_word_nearest's exactness argument needs both bounds): every pixel
+#define CP_ROWS_MAX 256           // rows of a range (frames up to 4096 rows: 4096 / 16)
+__device__ __forceinline__ unsigned long long mt_key(int x, int y, int out_w, float px, float py) {
+    const float dx = (float)(x + 1) - px, dy = (float)(y + 1) - py;
+    return ((unsigned long long)__float_as_uint(dx * dx + dy * dy) << 32) | (unsigned)(y * out_w + x);
+}
+template <bool WORDWISE>      // false: frames wider or taller than 4096 pixels (the exactness argument needs both bounds): every pixel
 __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict__ bits_all, const int* __restrict__ rect,
                                                       const int* __restrict__ valid, const unsigned long long* __restrict__ sums,
                                                       const int* __restrict__ img, const int* __restrict__ offset,
@@ -265,6 +271,7 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
                                                       int words_per_row, unsigned long long* __restrict__ keys,
                                                       int* __restrict__ cent_out, int* __restrict__ mass_out) {
     __shared__ int cent[MT_TARGETS][2];
+    __shared__ int rfirst[CP_ROWS_MAX], rlast[CP_ROWS_MAX];        // first / last set bit (frame column) of the range's rows, -1: empty row
     const int n = *total < n_max ? *total : n_max;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -284,17 +291,31 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
         int j1 = offset[img[i] + 1];
         j1 = j1 < n ? j1 : n;
         const int nt = j1 - j0 < MT_TARGETS ? j1 - j0 : MT_TARGETS;   // kd <= 100 targets per image (apse_create)
-        __syncthreads();                                            // the previous mask's centroids are no longer read
+        const int rpp = (rows + P - 1) / P;
+        const int pb = ry0 + (int)blockIdx.x * rpp;
+        const int pe = pb + rpp < ry1 ? pb + rpp : ry1;
+        const int w0 = rx0 >> 6, w1 = (rx1 + 63) >> 6;
+        const uint64_t* bits = bits_all + (size_t)i * out_h * words_per_row;
+        __syncthreads();                                            // the previous mask's tables are no longer read
         for (int t = threadIdx.x; t < nt; t += blockDim.x) {
             const unsigned long long m = sums[(j0 + t) * 3], sx = sums[(j0 + t) * 3 + 1], sy = sums[(j0 + t) * 3 + 2];
             cent[t][0] = m ? (int)(sx / m) : -1;
             cent[t][1] = m ? (int)(sy / m) : -1;
         }
+        if (WORDWISE) {
+            for (int r = threadIdx.x; r < pe - pb && r < CP_ROWS_MAX; r += blockDim.x) {
+                const uint64_t* row = bits + (size_t)(pb + r) * words_per_row;
+                int f = -1, l = -1;
+                for (int w = w0; w < w1; ++w) {
+                    const uint64_t word = row[w];
+                    if (!word) continue;
+                    if (f < 0) f = (w << 6) + __ffsll((long long)word) - 1;
+                    l = (w << 6) + 63 - __clzll((long long)word);
+                }
+                rfirst[r] = f; rlast[r] = l;
+            }
+        }
         __syncthreads();
-        const int rpp = (rows + P - 1) / P;
-        const int pb = ry0 + (int)blockIdx.x * rpp;
-        const int pe = pb + rpp < ry1 ? pb + rpp : ry1;
-        const int w0 = rx0 >> 6, nw = ((rx1 + 63) >> 6) - w0;
         const int ngroups = (nt + 7) >> 3;
         // few target groups: the four waves split the rows of the range instead of the groups
         const int wsplit = ngroups >= 3 ? 1 : (ngroups == 2 ? 2 : 4);
@@ -302,8 +323,7 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
         const int srows = (pe - pb + wsplit - 1) / wsplit;
         const int yb = pb + sub * srows;
         const int nrows = (yb + srows < pe ? yb + srows : pe) - yb;
-        if (nrows <= 0) continue;                                   // wave-uniform; no barrier before the loop top's (every wave reaches it)
-        const uint64_t* bits = bits_all + (size_t)i * out_h * words_per_row;
+        if (nrows <= 0) continue;                                   // wave-uniform; every wave still reaches the barriers at the loop top
         for (int jg = (wave / wsplit) * 8; jg < nt; jg += (4 / wsplit) * 8) {
             float px[8], py[8];
             unsigned long long b[8];
@@ -314,35 +334,53 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
                 py[k] = ok ? (float)cent[jg + k][1] : 0.f;
                 b[k] = ~0ull;
             }
-            int ry = lane / nw, wx = lane - ry * nw;                  // word `lane` of the range, advanced by 64 words per step
-            const int dry = 64 / nw, dwx = 64 - dry * nw;
-            for (; ry < nrows; ) {
-                const int y = yb + ry, w = w0 + wx;
-                uint64_t word = bits[(size_t)y * words_per_row + w];
-                if (word) {
-                    if (WORDWISE) {
+            if (WORDWISE) {
+                for (int ry = lane; ry < nrows; ry += 64) {
+                    const int y = yb + ry;
+                    const int f = rfirst[y - pb], l = rlast[y - pb];
+                    if (f < 0) continue;
+                    const uint64_t* row = bits + (size_t)y * words_per_row;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int c = (int)px[k] - 1;                  // the target's column (0-based)
+                        unsigned long long key;
+                        if (c <= f) key = mt_key(f, y, out_w, px[k], py[k]);
+                        else if (c >= l) key = mt_key(l, y, out_w, px[k], py[k]);
+                        else {
+                            // f < c < l: a set bit exists on both sides.  Nearest at or left of c, nearest right of c.
+                            int w = c >> 6;
+                            const int r = c & 63;
+                            uint64_t word = row[w];
+                            uint64_t m = r >= 63 ? word : (word & ((2ull << r) - 1ull));
+                            int ww = w;
+                            while (!m) m = row[--ww];                  // ends at the first bit's word at the latest
+                            const int xl = (ww << 6) + 63 - __clzll((long long)m);
+                            m = r >= 63 ? 0ull : ((word >> (r + 1)) << (r + 1));
+                            ww = w;
+                            while (!m) m = row[++ww];                  // ends at the last bit's word at the latest
+                            const int xr = (ww << 6) + __ffsll((long long)m) - 1;
+                            const unsigned long long kl = mt_key(xl, y, out_w, px[k], py[k]), kr = mt_key(xr, y, out_w, px[k], py[k]);
+                            key = kl < kr ? kl : kr;
+                        }
+                        b[k] = key < b[k] ? key : b[k];
+                    }
+                }
+            } else {
+                const int nw = w1 - w0;
+                for (int t = lane; t < nw * nrows; t += 64) {
+                    const int ry = t / nw, w = w0 + (t - ry * nw);
+                    const int y = yb + ry;
+                    uint64_t word = bits[(size_t)y * words_per_row + w];
+                    while (word) {
+                        const int bit = __ffsll((long long)word) - 1;
+                        word &= word - 1;
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
-                            const unsigned long long key = mt_word_nearest(word, w, y, out_w, px[k], py[k]);
+                            const unsigned long long key = mt_key((w << 6) + bit, y, out_w, px[k], py[k]);
                             b[k] = key < b[k] ? key : b[k];
-                        }
-                    } else {
-                        while (word) {
-                            const int bit = __ffsll((long long)word) - 1;
-                            word &= word - 1;
-                            const int x = (w << 6) + bit;
-                            const unsigned lin = (unsigned)(y * out_w + x);
-#pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                const float dx = (float)(x + 1) - px[k], dy = (float)(y + 1) - py[k];
-                                const unsigned long long key = ((unsigned long long)__float_as_uint(dx * dx + dy * dy) << 32) | lin;
-                                b[k] = key < b[k] ? key : b[k];
-                            }
                         }
                     }
                 }
-                ry += dry; wx += dwx;
-                if (wx >= nw) { wx -= nw; ++ry; }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
