@@ -256,9 +256,14 @@ __device__ __forceinline__ unsigned long long mt_word_nearest(uint64_t word, int
 //     the record (apse_read_results_end).  No scans, no item search, no block barrier in the loop.
 // Block (i, 0) writes detection i's centroid -- (floor(sum_x / mass), floor(sum_y / mass)) or (-1, -1) for an empty mask -- and
 // mass to the record.
+#ifndef CP_PARTS
 #define CP_PARTS 16               // row ranges per mask (grid x)
-#define CP_ROWS_MIN 16            // rows per range before a mask is cut further
-#define CP_ROWS_MAX 256           // rows of a range (frames up to 4096 rows: 4096 / 16)
+#endif
+#ifndef CP_ROWS_MIN
+#define CP_ROWS_MIN 16            // rows per range before a mask is cut further (sweep, us per 4 frames at ~38 detections per frame:
+#endif                            // 16 parts / 16 rows 102, 32 / 8 164, 64 / 4 310: the per-block prologue is what more blocks multiply)
+#define CP_LDS_WORDS 6144         // words of a row range kept in LDS (48 KB): the walks along sparse rows then never leave the CU
+#define CP_ROWS_MAX 256           // rows of a range (frames up to 4096 rows: 4096 / CP_PARTS fits with room)
 __device__ __forceinline__ unsigned long long mt_key(int x, int y, int out_w, float px, float py) {
     const float dx = (float)(x + 1) - px, dy = (float)(y + 1) - py;
     return ((unsigned long long)__float_as_uint(dx * dx + dy * dy) << 32) | (unsigned)(y * out_w + x);
@@ -271,7 +276,8 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
                                                       int words_per_row, unsigned long long* __restrict__ keys,
                                                       int* __restrict__ cent_out, int* __restrict__ mass_out) {
     __shared__ int cent[MT_TARGETS][2];
-    __shared__ int rfirst[CP_ROWS_MAX], rlast[CP_ROWS_MAX];        // first / last set bit (frame column) of the range's rows, -1: empty row
+    __shared__ int rfirst[CP_ROWS_MAX], rlast[CP_ROWS_MAX];        // first / last set bit (frame column) of the range's rows; empty row: last = -1
+    __shared__ uint64_t lw[WORDWISE ? CP_LDS_WORDS : 1];           // the range's words, row-major [rows][nw]
     const int n = *total < n_max ? *total : n_max;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -302,17 +308,25 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
             cent[t][0] = m ? (int)(sx / m) : -1;
             cent[t][1] = m ? (int)(sy / m) : -1;
         }
+        const int nw = w1 - w0;
+        const bool in_lds = WORDWISE && (pe - pb) * nw <= CP_LDS_WORDS;
         if (WORDWISE) {
-            for (int r = threadIdx.x; r < pe - pb && r < CP_ROWS_MAX; r += blockDim.x) {
-                const uint64_t* row = bits + (size_t)(pb + r) * words_per_row;
-                int f = -1, l = -1;
-                for (int w = w0; w < w1; ++w) {
-                    const uint64_t word = row[w];
-                    if (!word) continue;
-                    if (f < 0) f = (w << 6) + __ffsll((long long)word) - 1;
-                    l = (w << 6) + 63 - __clzll((long long)word);
+            for (int r = threadIdx.x; r < pe - pb && r < CP_ROWS_MAX; r += blockDim.x) { rfirst[r] = 0x7fffffff; rlast[r] = -1; }
+            __syncthreads();
+            // one coalesced pass over the range's words: every word goes to LDS (when the range fits) and bids for its row's first /
+            // last set bit with LDS atomics -- all loads independent (a thread walking its row word by word made this pass a chain of
+            // 20-60 dependent round trips per block)
+            int ry = (int)threadIdx.x / nw, wx = (int)threadIdx.x - ry * nw;
+            const int dry = 256 / nw, dwx = 256 - dry * nw;
+            for (int t = threadIdx.x; t < (pe - pb) * nw; t += 256) {
+                const uint64_t word = bits[(size_t)(pb + ry) * words_per_row + w0 + wx];
+                if (in_lds) lw[t] = word;
+                if (word && ry < CP_ROWS_MAX) {
+                    atomicMin(&rfirst[ry], ((w0 + wx) << 6) + __ffsll((long long)word) - 1);
+                    atomicMax(&rlast[ry], ((w0 + wx) << 6) + 63 - __clzll((long long)word));
                 }
-                rfirst[r] = f; rlast[r] = l;
+                ry += dry; wx += dwx;
+                if (wx >= nw) { wx -= nw; ++ry; }
             }
         }
         __syncthreads();
@@ -338,8 +352,9 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
                 for (int ry = lane; ry < nrows; ry += 64) {
                     const int y = yb + ry;
                     const int f = rfirst[y - pb], l = rlast[y - pb];
-                    if (f < 0) continue;
-                    const uint64_t* row = bits + (size_t)y * words_per_row;
+                    if (l < 0) continue;
+                    const uint64_t* grow = bits + (size_t)y * words_per_row;       // the row in the bit plane ...
+                    const int lbase = (y - pb) * nw - w0;                          // ... and in LDS: lw[lbase + frame word]
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const int c = (int)px[k] - 1;                  // the target's column (0-based)
@@ -348,16 +363,16 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
                         else if (c >= l) key = mt_key(l, y, out_w, px[k], py[k]);
                         else {
                             // f < c < l: a set bit exists on both sides.  Nearest at or left of c, nearest right of c.
-                            int w = c >> 6;
+                            const int w = c >> 6;
                             const int r = c & 63;
-                            uint64_t word = row[w];
+                            const uint64_t word = in_lds ? lw[lbase + w] : grow[w];
                             uint64_t m = r >= 63 ? word : (word & ((2ull << r) - 1ull));
                             int ww = w;
-                            while (!m) m = row[--ww];                  // ends at the first bit's word at the latest
+                            while (!m) { --ww; m = in_lds ? lw[lbase + ww] : grow[ww]; }      // ends at the first bit's word at the latest
                             const int xl = (ww << 6) + 63 - __clzll((long long)m);
                             m = r >= 63 ? 0ull : ((word >> (r + 1)) << (r + 1));
                             ww = w;
-                            while (!m) m = row[++ww];                  // ends at the last bit's word at the latest
+                            while (!m) { ++ww; m = in_lds ? lw[lbase + ww] : grow[ww]; }      // ends at the last bit's word at the latest
                             const int xr = (ww << 6) + __ffsll((long long)m) - 1;
                             const unsigned long long kl = mt_key(xl, y, out_w, px[k], py[k]), kr = mt_key(xr, y, out_w, px[k], py[k]);
                             key = kl < kr ? kl : kr;
@@ -366,7 +381,6 @@ __global__ __launch_bounds__(256) void closest_points(const uint64_t* __restrict
                     }
                 }
             } else {
-                const int nw = w1 - w0;
                 for (int t = lane; t < nw * nrows; t += 64) {
                     const int ry = t / nw, w = w0 + (t - ry * nw);
                     const int y = yb + ry;

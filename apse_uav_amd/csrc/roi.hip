@@ -262,20 +262,18 @@ __global__ __launch_bounds__(256) void roi_pool_nhwc(const void* __restrict__ fe
             m[2] = v[2] > m[2] ? v[2] : m[2];
             m[3] = v[3] > m[3] ? v[3] : m[3];
         };
-        // eight cell loads in flight per lane (round 4: two per iteration left the kernel waiting -- SQ counters at ~38 detections per
-        // frame, batch 4: 84 % of the wave time parked, 105 us); cells past the end of the row re-read its last cell (max is idempotent)
+        // two cell loads in flight per lane.  (Round 4: eight in flight measured SLOWER, 105 -> 118 us per 4 frames at ~38 detections
+        // per frame -- the kernel waits (84 % of its wave time parked) because it moves ~1.4 GB of cell rows per launch through L2
+        // (boxes hundreds of pixels wide max-pooled on the stride-4 map: the reference's choice of p2), not for want of requests.)
         for (int y = hs + wave; y < he; y += 4) {
-            const size_t frow = f + (size_t)y * W * 256;
-            for (int x = ws; x < we; x += 8) {
-                f32x4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int xx = x + u < we ? x + u : we - 1;
-                    v[u] = apse_ld4(feat, frow + (size_t)xx * 256, st);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) mx(v[u]);
+            int x = ws;
+            for (; x + 1 < we; x += 2) {
+                const f32x4 v0 = apse_ld4(feat, f + ((size_t)y * W + x) * 256, st);
+                const f32x4 v1 = apse_ld4(feat, f + ((size_t)y * W + x + 1) * 256, st);
+                mx(v0);
+                mx(v1);
             }
+            if (x < we) mx(apse_ld4(feat, f + ((size_t)y * W + x) * 256, st));
         }
         part[wave][lane] = m;
         __syncthreads();
