@@ -416,6 +416,16 @@ static int run_plan(apse_ctx* c, std::vector<Step>& plan, int batch, hipStream_t
                 // grid computes every tile the same way); tile shape and K split are plan constants (add_conv)
                 const int mh = (c->hint_total > 0 ? c->hint_total : 1) * p.m_per_item;
                 p.m_hint = mh < p.M ? mh : p.M;
+                // 16-bit modes, unsplit layers (round 4): the plan shapes these GEMMs for 8 detections per image; a frame with 40
+                // has five times the rows, and 64x64 tiles then run at half the rate of 128x128 ones.  The single-k-group 4-wave
+                // tiles (128x128, 64x64, 128x64) add every accumulator's products in the same ascending-k order -- the same bits
+                // (tests/test_gpu_ops.py::test_conv2d_16bit_tiles_are_bit_identical) -- so the tile may follow the hinted row count
+                // without a frame's results depending on what ran before it.  f32 (two-k-group shapes, split K) keeps the plan's.
+                if (p.prec != 0 && p.splitk == 1 && (cfg == 0 || cfg == 1 || cfg == 3)) {
+                    int sk_dyn = 1;
+                    const int cfg_dyn = apse_conv_pick_cfg(p.m_hint, p.Cout, p.steps_total, &sk_dyn);
+                    if (sk_dyn == 1 && (cfg_dyn == 0 || cfg_dyn == 1 || cfg_dyn == 3)) cfg = cfg_dyn;
+                }
             }
             else if (st.c.count_kind == 1 && batch == 1) p.m_count = propcnt_dev;
             int e0 = -1;

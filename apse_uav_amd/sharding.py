@@ -94,8 +94,15 @@ def gather_records(records, rank, world, device, kd=100, edim=128, unpack=True):
     buf = torch.zeros((mx,), dtype=torch.float32)
     buf[:flat.size] = torch.from_numpy(flat)
     buf = buf.to(device)
-    parts = [torch.empty((mx,), dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, parts, dst=0)
+    import os
+    if os.environ.get("APSE_GATHER", "gather") == "all_gather":
+        # diagnostic switch: the same payload with all_gather_into_tensor (every rank receives it) instead of a gather to rank 0
+        allb = torch.empty((world * mx,), dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(allb, buf)
+        parts = list(allb.view(world, mx)) if rank == 0 else None
+    else:
+        parts = [torch.empty((mx,), dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, parts, dst=0)
     if rank != 0:
         return None
     h = np.concatenate([parts[r].cpu().numpy()[:int(sizes[r][1])] for r in range(world)]) if world else flat

@@ -166,6 +166,27 @@ def test_conv2d_16bit_storage(case, prec, logdir):
         assert err_stats(out32, ref32)["rel_to_max"] < 2e-5
 
 
+@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(3, 256, 28, 28, 256, 3, 1), (5, 256, 14, 14, 256, 3, 1), (2, 256, 37, 31, 1024, 1, 0), (1, 512, 20, 26, 128, 3, 1)])
+def test_conv2d_16bit_tiles_are_bit_identical(shape, prec):
+    """16-bit operands, unsplit: the single-k-group 4-wave tiles -- 128x128 (cfg 0), 64x64 (cfg 1), 128x64 (cfg 3) -- add every
+    accumulator's products in the same ascending-k order, so they must give the SAME BITS (ragged M, residual, ReLU included).  The
+    library relies on it: for the GEMMs over the packed detection list the tile follows the hinted row count (detector.hip run_plan),
+    and a frame's results must not depend on that hint."""
+    from hip_helpers import hip_conv2d
+    B, Cin, H, W, Cout, K, pad = shape
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + K)
+    dt = torch.bfloat16 if prec == 1 else torch.float16
+    r16 = lambda t: t.to(dt).to(torch.float32)
+    x = r16(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    res = r16(torch.randn(B, Cout, H, W, generator=g))
+    outs = [hip_conv2d(x, w, b, 1, pad, True, res, 1, cfg, 0, prec=prec, x_st=prec, res_st=prec, y_st=prec) for cfg in (0, 1, 3)]
+    assert int(torch.isnan(outs[0]).sum()) == 0 and float(outs[0].abs().max()) > 0
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 STREAM_CASES = [
     # name, B, Cin (= K), H, W, Cout, stride, relu, res_mode      -- the memory-streaming 1x1 kernel (csrc/conv1x1_stream.hip, cfg 9)
     ("s_k64_n256_res", 1, 64, 24, 40, 256, 1, True, 1),          # res2 conv3: residual + ReLU
