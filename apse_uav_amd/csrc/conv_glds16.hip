@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
     typedef typename std::conditional<PR == 1, bf16x8, g16_f16x8>::type op8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int GL_STAGE = (GL_BM + GL_BN) * 128;   // bytes per stage: 64 elements (128 B) per tile row
-    constexpr int GL_NS = GL_BN == 128 ? 3 : 2;
+    constexpr int GL_NS = (GL_BM + GL_BN) * 128 * 3 <= 160 * 1024 ? 3 : 2;      // three stages where they fit (all but 256 x 256)
     constexpr int WNW = GL_BN / 64;                   // waves along N (64 columns each)
     constexpr int TMW = (GL_BM / (8 / WNW)) / 32;     // 32-row MFMA tiles per wave along M: 1 (128 x 128), 2 (256 x 128) or 4 (256 x 256)
     constexpr int APW = GL_BM / 64, BPW = GL_BN / 64; // DMA pieces (8-row groups) per wave and stage: A 2 or 4, B 2 or 4
@@ -273,7 +273,7 @@ bool apse_conv_glds16_ok(const ConvParams& p) {
 
 template <int PR, int BM, int BN>
 static int launch_glds(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    const size_t lds_ring = (size_t)(BN == 128 ? 3 : 2) * (BM + BN) * 128, lds_c = (size_t)BM * (128 + 4) * sizeof(float);
+    const size_t lds_ring = (size_t)((BM + BN) * 128 * 3 <= 160 * 1024 ? 3 : 2) * (BM + BN) * 128, lds_c = (size_t)BM * (128 + 4) * sizeof(float);
     const size_t lds = lds_ring > lds_c ? lds_ring : lds_c;
     static bool attr_done = false;
     if (!attr_done) {
@@ -299,8 +299,18 @@ bool apse_conv_glds16_small(const ConvParams& p) {
     return !off && ((p.M + 255) / 256) * ((p.Cout + 127) / 128) < 200;
 }
 
+// 128 x 256 tiles (round 4): every output column in one tile, so the activation rows -- which come from beyond L2 at ~30 GB/s per
+// CU (MI355X_MICROARCH.md, "Indexed rows: gather into LDS"), the rate that paces these kernels -- are fetched ONCE, and half as many
+// rows per tile keep all CUs busy where 256-row tiles would not.  For N = 256 layers with about one such tile per CU.
+bool apse_conv_glds16_tall(const ConvParams& p) {
+    static const bool off = getenv("APSE_GLDS_NO128X256") != nullptr;     // A/B switch for the sweeps
+    const int t = ((p.M + 127) / 128) * (p.Cout / 256);
+    return !off && p.Cout == 256 && t >= 200 && t <= 640;
+}
+
 int apse_launch_conv_glds16(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (apse_conv_glds16_wide(p)) return p.prec == 1 ? launch_glds<1, 256, 256>(p, s, ev0, ev1) : launch_glds<2, 256, 256>(p, s, ev0, ev1);
+    if (apse_conv_glds16_tall(p)) return p.prec == 1 ? launch_glds<1, 128, 256>(p, s, ev0, ev1) : launch_glds<2, 128, 256>(p, s, ev0, ev1);
     if (apse_conv_glds16_small(p)) return p.prec == 1 ? launch_glds<1, 128, 128>(p, s, ev0, ev1) : launch_glds<2, 128, 128>(p, s, ev0, ev1);
     return p.prec == 1 ? launch_glds<1, 256, 128>(p, s, ev0, ev1) : launch_glds<2, 256, 128>(p, s, ev0, ev1);
 }

@@ -61,6 +61,9 @@ CONV_CASES = [
     ("g_256x128_1x1_k512", 1, 512, 228, 230, 136, 1, 1, 0, False, 0, 11, 0),  # 8 stages, Cout not a multiple of the tile (2 x 205 tiles)
     ("g_128x128_two_stages", 2, 128, 31, 29, 256, 1, 1, 0, True, 1, 11, 0),   # T = 2: prologue and drain of the ping-pong loop only
     ("g_128x128_one_stage", 1, 64, 40, 44, 128, 1, 1, 0, False, 0, 11, 0),    # T = 1
+    # 128x256 tile (Cout = 256 and 200..640 tiles of 128 rows): every output column in one tile, three stages of 48 KB
+    ("g_128x256_tall", 1, 64, 161, 160, 256, 3, 1, 1, True, 1, 11, 0),       # 202 tiles, ragged last one, residual
+    ("g_128x256_1x1_k512", 1, 512, 163, 161, 256, 1, 1, 0, False, 0, 11, 0),  # 8 stages
 ]
 
 
