@@ -201,6 +201,11 @@ STREAM_CASES = [
     ("s_k64_n128", 3, 64, 9, 11, 128, 1, True, 0),               # a single chunk
     ("s_k256_n256_bigmap", 1, 256, 184, 180, 256, 1, False, 2),
     ("s_k256_n64_bigmap", 1, 256, 182, 181, 64, 1, True, 0),     # res2 conv1 shape class (f32 only: N = 64 needs the 64-column chunks)
+    # round 4: the fp16 batch-8 res4 conv3 itself (263 row blocks, one per CU) and ragged / split-N neighbours of it
+    ("s_k256_n1024_res4_b8", 8, 256, 50, 84, 1024, 1, True, 1),
+    ("s_k256_n1024_pairs", 1, 256, 64, 128, 1024, 1, True, 1),
+    ("s_k256_n1024_ragged", 1, 256, 97, 127, 1024, 1, False, 1),
+    ("s_k256_n512_small", 3, 256, 23, 29, 512, 1, True, 1),
     ("s_k128_n192", 2, 128, 15, 13, 192, 1, True, 1),            # f32 only: N a multiple of 64, not of 128  # FPN lateral 2 shape class: >= 32768 rows per image (f32 takes K = 256 there)
 ]
 
