@@ -22,6 +22,7 @@
 #include <type_traits>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 s1_zero16() { return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ f32x16 s1_mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 s1_mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
@@ -104,11 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
     const int erow = lane >> 3, ecol = (lane & 7) * 8;          // epilogue: lane -> (row erow + 8 i, columns ecol .. ecol + 7)
     int g = 0;
     for (int ch = c_begin; ch < c_end; ++ch) {
-        f32x16 acc[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+        f32x16 acc[NJ];                 // written by the chunk's first MFMAs (C operand = the constant 0)
 #pragma unroll
         for (int s = 0; s < NST; ++s, ++g) {
             const int buf = g & 1;
@@ -130,13 +127,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
                     typedef typename std::conditional<PR == 1, bf16x8, f16x8>::type op8;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        acc[j] = s1_mfma16(__builtin_bit_cast(op8, a[s][c]), __builtin_bit_cast(op8, bfr[j]), acc[j]);
+                        acc[j] = s1_mfma16(__builtin_bit_cast(op8, a[s][c]), __builtin_bit_cast(op8, bfr[j]), (s == 0 && c == 0) ? s1_zero16() : acc[j]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
                         for (int j = 0; j < NJ; ++j)
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][c][k], bfr[j][k], acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][c][k], bfr[j][k], (s == 0 && c == 0 && k == 0) ? s1_zero16() : acc[j], 0, 0, 0);
                 }
             }
             __syncthreads();
@@ -205,8 +202,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
                     }
                 }
                 if (p.relu) {
+                    // x > 0 ? x : 0 as ONE v_max_f32 with the constant first (-0 and NaN give +0, like the select).  Written in C the
+                    // compiler puts a canonicalising v_max x, x in front of it (IEEE mode): 128 instead of 64 instructions per chunk
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { v0[k] = v0[k] > 0.f ? v0[k] : 0.f; v1[k] = v1[k] > 0.f ? v1[k] : 0.f; }
+                    for (int k = 0; k < 4; ++k) {
+                        asm("v_max_f32 %0, 0, %1" : "=v"(v0[k]) : "v"(v0[k]));
+                        asm("v_max_f32 %0, 0, %1" : "=v"(v1[k]) : "v"(v1[k]));
+                    }
                 }
                 if (m < M) {
                     const size_t yi = (size_t)m * N + nb;
