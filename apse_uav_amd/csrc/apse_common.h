@@ -22,8 +22,6 @@ struct ConvParams {
     const float* x;
     const float* w;
     const uint16_t* w16;  // same layout as w, pre-rounded to bf16 (bf16 kernel only; nullptr -> round w on the fly)
-    const uint16_t* w16s; // the same 16-bit filters STAGE-MAJOR: [KH * KWCp / 64 k-stages][Cout_p][64] -- a stage's rows are one contiguous run, so
-                          // every LDS-DMA piece of conv_glds16 (8 filter rows x 128 B) is a contiguous 1 KB read (nullptr, or KWCp % 64 != 0: w16)
     const float* bias;    // [Cout_p] or nullptr
     const float* res;     // residual (res_mode != 0)
     float* y;

@@ -73,7 +73,6 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
     const int steps_per_row = p.KWCp >> 6;
     const int T = (GL_ABLATE == 6) ? 2 : p.KH * steps_per_row;      // 6: two stages only = the fixed per-tile cost
     const size_t w_row = (size_t)p.KH * p.KWCp;
-    const unsigned stage_bytes = (unsigned)((p.Cout + 127) & ~127) * 128u;       // one k-stage of the stage-major filter copy
 
     // ---- this lane's DMA rows: A groups 4 wave .. 4 wave + 3, B groups 2 wave, 2 wave + 1 (a group = 8 rows x 128 B = one
     // wave instruction); LDS slot (row, lane & 7) receives chunk cs = (lane & 7) ^ swz(row)
@@ -99,13 +98,12 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
     for (int i = 0; i < BPW; ++i) {
         const int row = (wave * BPW + i) * 8 + (lane >> 3);
         const int cs = ((lane & 7) ^ ((row >> 1) & 7)) << 3;
-        b_off[i] = p.w16s ? (unsigned)(((n0 + row) * 64 + cs) << 1)                 // stage-major copy: row stride 128 B inside a stage
-                          : (unsigned)((((size_t)(n0 + row) * w_row) + cs) << 1);    // bytes; filters are padded to Cout_p = 128 k rows
+        b_off[i] = (unsigned)((((size_t)(n0 + row) * w_row) + cs) << 1);       // bytes; filters are padded to Cout_p = 128 k rows
     }
     __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0,
                                                                     (int)(((unsigned)(p.B * p.H * p.W) << p.cin_log2) << 1), 0x00020000);
-    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w16s ? p.w16s : p.w16), 0,
-                                                                    (int)((((unsigned)(p.w16s ? ((p.Cout + 127) & ~127) : tiles_n * GL_BN)) * (unsigned)w_row) << 1), 0x00020000);
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w16), 0,
+                                                                    (int)((((unsigned)(tiles_n * GL_BN)) * (unsigned)w_row) << 1), 0x00020000);
     int ld_r = 0, ld_q = 0;
     // One DMA "piece" = one wave instruction (8 rows x 128 B).  Pieces 0..APW-1: this wave's A groups, APW..: its B groups.
     // piece 0 also computes the step's scalars and advances (filter row, step) -- pieces of a stage are issued in order.
@@ -116,7 +114,7 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
             cur_q0 = ld_q << 6;                                      // element offset of this step inside the filter row's run
             cur_r = ld_r;
             cur_rowoff = ((ld_r * p.W) << p.cin_log2) + cur_q0;
-            cur_woff = p.w16s ? (unsigned)(ld_r * steps_per_row + ld_q) * stage_bytes : (unsigned)((ld_r * p.KWCp + cur_q0) << 1);
+            cur_woff = (unsigned)((ld_r * p.KWCp + cur_q0) << 1);
             if (++ld_q == steps_per_row) { ld_q = 0; ++ld_r; }
         }
         if (j < APW) {

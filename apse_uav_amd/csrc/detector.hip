@@ -53,7 +53,6 @@ int apse_k_roi_align(const FpnMaps*, const float*, const int*, const int*, const
 int apse_k_roi_pool(const void*, int, int, int, const float*, const int*, const int*, int, int, float, float*, int, int, hipStream_t);
 int apse_k_mask_resize(const uint8_t*, int, int, int, int, int, float*, hipStream_t);
 int apse_k_round16(const float*, uint16_t*, size_t, int, hipStream_t);
-int apse_k_stage_major16(const uint16_t*, uint16_t*, int, int, hipStream_t);
 int apse_k_roi_align_masked(const void*, int, int, int, int, const float*, const float*, int, int, int, float, float*, hipStream_t);
 int apse_k_l2_normalize(const float*, float*, int, const int*, int, hipStream_t);
 int apse_k_sqdist(const float*, const float*, int, int, int, float*, hipStream_t);
@@ -312,21 +311,11 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     const bool use_bf16 = (c->cfg.compute_dtype >= 1 && Cout > 32 && sp.name != "assoc_fc");      // bf16 or f16 operands
     float* wd = nullptr;
     uint16_t* wd16 = nullptr;
-    uint16_t* wd16s = nullptr;
     if (use_bf16) {
         // filters pre-rounded to the 16-bit operand type (round-to-nearest-even, as the in-kernel converts do)
         std::vector<uint16_t> p16(packed.size());
         for (size_t i = 0; i < packed.size(); ++i) p16[i] = round16(packed[i], c->cfg.compute_dtype);
         wd16 = dupload(c, p16);
-        // a second, stage-major copy for the LDS-DMA kernel (conv_glds16: k-stages of 64 elements; apse_common.h w16s)
-        const size_t w_row = (size_t)KH * KWCp;
-        if (wd16 && (KWCp & 63) == 0 && cin_p >= 64 && !getenv("APSE_NO_STAGE_MAJOR")) {
-            std::vector<uint16_t> ps(p16.size());
-            for (int n = 0; n < Cout_p; ++n)
-                for (size_t k = 0; k < w_row; ++k) ps[((k >> 6) * Cout_p + n) * 64 + (k & 63)] = p16[(size_t)n * w_row + k];
-            wd16s = dupload(c, ps);
-            if (!wd16s) return fail(c, APSE_E_NOMEM, "weight upload failed at " + sp.name);
-        }
     } else {
         wd = dupload(c, packed);
     }
@@ -341,7 +330,7 @@ static int add_conv(apse_ctx* c, std::vector<Step>& plan, const ConvSpec& sp, co
     cs.b_mult = in_items_mult;
     cs.count_kind = count_kind;
     ConvParams& p = cs.p;
-    p.x = in.p; p.w = wd; p.w16 = wd16; p.w16s = wd16s; p.bias = bd; p.res = res ? res->p : nullptr; p.res_mode = res_mode;
+    p.x = in.p; p.w = wd; p.w16 = wd16; p.bias = bd; p.res = res ? res->p : nullptr; p.res_mode = res_mode;
     p.x_st = in.st; p.res_st = res ? res->st : 0;
     p.H = in.H; p.W = in.W; p.cin_log2 = apse_ilog2(cin_p);
     p.KH = KH; p.KW = KW; p.stride = sp.stride; p.pad = sp.pad; p.KWCp = KWCp;
@@ -1389,17 +1378,12 @@ int apse_conv2d(const apse_conv_desc* d, const float* x, const float* w, const f
         hipDeviceSynchronize();
         if (d16) hipFree(d16);
         d16 = nullptr; d16_cap = 0;
-        if (hipMalloc(reinterpret_cast<void**>(&d16), ne * 2 * 2) != hipSuccess) return APSE_E_NOMEM;      // rounded copy + its stage-major copy
+        if (hipMalloc(reinterpret_cast<void**>(&d16), ne * 2) != hipSuccess) return APSE_E_NOMEM;
         d16_cap = ne;
     }
     int rc = apse_k_round16(w, d16, ne, p.prec, (hipStream_t)stream);
     if (rc) return rc;
     p.w16 = d16;
-    if ((p.KWCp & 63) == 0 && !getenv("APSE_NO_STAGE_MAJOR")) {           // (read per call: the tests compare the two layouts)
-        rc = apse_k_stage_major16(d16, d16 + ne, apse_roundup(p.Cout, 128), p.KH * p.KWCp, (hipStream_t)stream);
-        if (rc) return rc;
-        p.w16s = d16 + ne;
-    }
     return apse_launch_conv(p, cfg, (hipStream_t)stream);
 }
 

@@ -433,23 +433,7 @@ __global__ __launch_bounds__(256) void round16_kernel(const float* __restrict__ 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) apse_st1(y, i, x[i], dtype);
 }
 
-// 16-bit filters [rows][w_row] -> stage-major [w_row / 64][rows][64] (ConvParams::w16s)
-__global__ __launch_bounds__(256) void stage_major16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int rows, int w_row) {
-    const size_t n = (size_t)rows * w_row;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int r = (int)(i / w_row), k = (int)(i - (size_t)r * w_row);
-        dst[((size_t)(k >> 6) * rows + r) * 64 + (k & 63)] = src[i];
-    }
-}
-
 extern "C" {
-int apse_k_stage_major16(const uint16_t* src, uint16_t* dst, int rows, int w_row, hipStream_t s) {
-    if (rows <= 0 || w_row <= 0 || (w_row & 63)) return APSE_E_INVALID;
-    size_t blocks = ((size_t)rows * w_row + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(stage_major16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, rows, w_row);
-    return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
-}
 int apse_k_round16(const float* x, uint16_t* y, size_t n, int dtype, hipStream_t s) {
     if (n == 0) return APSE_OK;
     size_t blocks = (n + 255) / 256;
