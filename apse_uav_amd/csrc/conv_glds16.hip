@@ -23,7 +23,7 @@ __device__ __forceinline__ f32x16 g16_mfma(bf16x8 a, bf16x8 b, f32x16 c) { retur
 __device__ __forceinline__ f32x16 g16_mfma(g16_f16x8 a, g16_f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 #ifndef GL_ABLATE
-#define GL_ABLATE 0      // diagnostics only (tools/gpu_glds_ablate.sh): 1 no MFMA, 2 DMAs of the first two stages only, 3 no fragment reads, 4 two of three A fetches out of range
+#define GL_ABLATE 0      // diagnostics only (tools/gpu_glds_ablate.sh): 1 no MFMA, 2 DMAs of the first two stages only, 3 no fragment reads, 4 two of three A fetches out of range, 5 no output stores, 6 two stages only
 #endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
