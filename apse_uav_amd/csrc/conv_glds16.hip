@@ -22,9 +22,6 @@ typedef _Float16 g16_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 g16_mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 g16_mfma(g16_f16x8 a, g16_f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-#ifndef GL_WARM
-#define GL_WARM 0        // > 0: 16-byte loads per thread of the start-of-kernel filter warm-up (A/B builds)
-#endif
 #ifndef GL_ABLATE
 #define GL_ABLATE 0      // diagnostics only (tools/gpu_glds_ablate.sh): 1 no MFMA, 2 DMAs of the first two stages only, 3 no fragment reads, 4 two of three A fetches out of range, 5 no output stores, 6 two stages only
 #endif
@@ -146,24 +143,6 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
     constexpr int AHEAD = GL_NS - 1;                  // stages in flight beyond the one being computed
-#if GL_WARM
-    // Every k-stage of the filter is a cold L2 miss for the XCD (the layer before streamed its maps through the 4 MB): the blocks of an
-    // XCD (blockIdx & 7) pull one slice each of the WHOLE filter into their L2 now, in parallel, instead of stage by stage two ahead.
-    {
-        const unsigned total = (unsigned)(tiles_n * GL_BN) * (unsigned)w_row * 2u;
-        const unsigned nsl = (gridDim.x + 7u) >> 3, idx = blockIdx.x >> 3;
-        const unsigned per = ((total + nsl - 1) / nsl + 1023u) & ~1023u;
-        const unsigned lo = idx * per, hi = lo + per < total ? lo + per : total;
-        f32x4 wv[GL_WARM];
-#pragma unroll
-        for (int i = 0; i < GL_WARM; ++i) {
-            const unsigned o = lo + (unsigned)(i * 512 + tid) * 16u;
-            wv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)(o + 16u <= hi ? o : 0xfffffff0u), 0, 0));
-        }
-#pragma unroll
-        for (int i = 0; i < GL_WARM; ++i) asm volatile("" ::"v"(wv[i]));
-    }
-#endif
     issue(0);
     if (AHEAD > 1 && T > 1) issue(1);
     for (int t = 0; t < T; ++t) {
