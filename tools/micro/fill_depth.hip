@@ -21,7 +21,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define STAGE_BYTES 16384     // 8 waves x 2 pieces x 1 KB
 #define P 2
 
-template <int DEPTH>
+// ROWB > 0: every wave instruction gathers 8 rows x 128 B at a row stride of ROWB bytes (the A operand of a 64-deep k step read
+// from an NHWC map of ROWB / 2 channels) instead of one contiguous 1 KB run; the region is swept exactly once per pass either way.
+template <int DEPTH, int ROWB = 0>
 __global__ __launch_bounds__(512) void fill_lds(const char* buf, unsigned region, int passes, unsigned* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NS = DEPTH + 1;
@@ -33,8 +35,15 @@ __global__ __launch_bounds__(512) void fill_lds(const char* buf, unsigned region
         const unsigned off = (unsigned)(t % per_pass) * STAGE_BYTES + wave * (P * 1024) + lane * 16;
         char* dst = smem + (t % NS) * STAGE_BYTES + wave * (P * 1024);
 #pragma unroll
-        for (int j = 0; j < P; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + j * 1024), 16, (int)(off + j * 1024), 0, 0, 0);
+        for (int j = 0; j < P; ++j) {
+            unsigned o = off + j * 1024;
+            if (ROWB > 0) {
+                const unsigned piece = ((unsigned)(t % per_pass) * STAGE_BYTES + wave * (P * 1024) + j * 1024) >> 10;   // 1 KB piece index in the region
+                constexpr unsigned SL = ROWB / 128;                                                                   // k slices per row
+                o = (piece / SL) * 8u * ROWB + (piece % SL) * 128u + (unsigned)(lane >> 3) * ROWB + (unsigned)(lane & 7) * 16u;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + j * 1024), 16, (int)o, 0, 0, 0);
+        }
     };
     for (int s = 0; s < DEPTH && s < T; ++s) issue(s);
     unsigned acc = 0;
@@ -133,6 +142,7 @@ int main() {
     K ks[] = {
         {"lds depth 1", fill_lds<1>, 16}, {"lds depth 2", fill_lds<2>, 32}, {"lds depth 3", fill_lds<3>, 48}, {"lds depth 4", fill_lds<4>, 64},
         {"lds depth 6", fill_lds<6>, 96}, {"lds depth 8", fill_lds<8>, 128},
+        {"lds d3 rows 512B", fill_lds<3, 512>, 48}, {"lds d3 rows 2KB", fill_lds<3, 2048>, 48}, {"lds d3 rows 4KB", fill_lds<3, 4096>, 48},
         {"reg R 2", fill_reg<2>, 16}, {"reg R 4", fill_reg<4>, 32}, {"reg R 8", fill_reg<8>, 64}, {"reg R 12", fill_reg<12>, 96},
         {"reg R 16", fill_reg<16>, 128}, {"reg R 24", fill_reg<24>, 192}, {"reg R 32", fill_reg<32>, 256},
         {"mix 6 dma+0", fill_mix<6, 0>, 96}, {"mix 4 dma+2 reg", fill_mix<4, 2>, 80}, {"mix 2 dma+4 reg", fill_mix<2, 4>, 64}, {"mix 0+6 reg", fill_mix<0, 6>, 48},
