@@ -22,6 +22,7 @@
 #include <type_traits>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned s1_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 s1_zero16() { return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ f32x16 s1_mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 s1_mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -103,6 +104,24 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
 
     float* cw = Cw + wave * 32 * CLD;
     const int erow = lane >> 3, ecol = (lane & 7) * 8;          // epilogue: lane -> (row erow + 8 i, columns ecol .. ecol + 7)
+    // Output and residual rows go through buffer descriptors: byte offsets of this lane's four rows once per block (rows past M get
+    // an offset beyond the range: the load returns zeros, the store is dropped) -- no branch and no 64-bit arithmetic per chunk.
+    constexpr unsigned ES = PR ? 2u : 4u, DEAD = 0x80000000u;      // (apse_conv1x1_stream_ok keeps every tensor below 0x70000000 bytes)
+    unsigned yrow[4], rrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + erow + 8 * i;
+        yrow[i] = m < M ? (unsigned)m * (unsigned)N * ES : DEAD;
+        rrow[i] = yrow[i];
+        if (p.res_mode == 2 && m < M) {
+            const int b = m / ohw, rem = m - b * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
+            rrow[i] = (unsigned)((b * (p.OH >> 1) + (oy >> 1)) * (p.OW >> 1) + (ox >> 1)) * (unsigned)N * ES;
+        }
+    }
+    const unsigned res_rows = p.res_mode == 2 ? (unsigned)(p.B * (p.OH >> 1) * (p.OW >> 1)) : (unsigned)M;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((unsigned)M * (unsigned)N * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0,
+                                                                           (int)(p.res ? res_rows * (unsigned)N * ES : 0u), 0x00020000);
     int g = 0;
     for (int ch = c_begin; ch < c_end; ++ch) {
         f32x16 acc[NJ];                 // written by the chunk's first MFMAs (C operand = the constant 0)
@@ -148,25 +167,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
             f32x4 rr[4][RV];
             if (p.res_mode != 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = m0 + erow + 8 * i;
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int q = 0; q < RV; ++q) rr[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (m < M) {
-                        size_t ridx;
-                        if (p.res_mode == 1) ridx = (size_t)m * N + nb;
-                        else {
-                            const int b = m / ohw, rem = m - b * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
-                            ridx = ((size_t)b * ((p.OH >> 1) * (p.OW >> 1)) + (oy >> 1) * (p.OW >> 1) + (ox >> 1)) * N + nb;
-                        }
-                        if constexpr (PR == 0) {
-                            rr[i][0] = *reinterpret_cast<const f32x4*>(p.res + ridx);
-                            rr[i][1] = *reinterpret_cast<const f32x4*>(p.res + ridx + 4);
-                        } else {
-                            rr[i][0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const uint16_t*>(p.res) + ridx);      // 8 x 16 bit
-                        }
-                    }
-                }
+                    for (int q = 0; q < RV; ++q)
+                        rr[i][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)(rrow[i] + (unsigned)nb * ES + q * 16u), 0, 0));
             }
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int r = erow + 8 * i, m = m0 + r;
+                const int r = erow + 8 * i;
                 f32x4 v0 = *reinterpret_cast<const f32x4*>(cw + r * CLD + ecol) + b0;
                 f32x4 v1 = *reinterpret_cast<const f32x4*>(cw + r * CLD + ecol + 4) + b1;
                 if (p.res_mode != 0) {
@@ -210,22 +214,20 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream(const ConvParams p, con
                         asm("v_max_f32 %0, 0, %1" : "=v"(v1[k]) : "v"(v1[k]));
                     }
                 }
-                if (m < M) {
-                    const size_t yi = (size_t)m * N + nb;
-                    if constexpr (PR == 0) {
-                        APSE_NT_STORE(v0, reinterpret_cast<f32x4*>(p.y + yi));
-                        APSE_NT_STORE(v1, reinterpret_cast<f32x4*>(p.y + yi + 4));
-                    } else if constexpr (PR == 1) {
-                        bf16x8 o;
-                        o[0] = (__bf16)v0[0]; o[1] = (__bf16)v0[1]; o[2] = (__bf16)v0[2]; o[3] = (__bf16)v0[3];
-                        o[4] = (__bf16)v1[0]; o[5] = (__bf16)v1[1]; o[6] = (__bf16)v1[2]; o[7] = (__bf16)v1[3];
-                        APSE_NT_STORE(o, reinterpret_cast<bf16x8*>(reinterpret_cast<uint16_t*>(p.y) + yi));
-                    } else {
-                        f16x8 o;
-                        o[0] = (_Float16)v0[0]; o[1] = (_Float16)v0[1]; o[2] = (_Float16)v0[2]; o[3] = (_Float16)v0[3];
-                        o[4] = (_Float16)v1[0]; o[5] = (_Float16)v1[1]; o[6] = (_Float16)v1[2]; o[7] = (_Float16)v1[3];
-                        APSE_NT_STORE(o, reinterpret_cast<f16x8*>(reinterpret_cast<uint16_t*>(p.y) + yi));
-                    }
+                const int yoff = (int)(yrow[i] + (unsigned)nb * ES);
+                if constexpr (PR == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(s1_u32x4, v0), yrsrc, yoff, 0, APSE_NT ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(s1_u32x4, v1), yrsrc, yoff + 16, 0, APSE_NT ? 2 : 0);
+                } else if constexpr (PR == 1) {
+                    bf16x8 o;
+                    o[0] = (__bf16)v0[0]; o[1] = (__bf16)v0[1]; o[2] = (__bf16)v0[2]; o[3] = (__bf16)v0[3];
+                    o[4] = (__bf16)v1[0]; o[5] = (__bf16)v1[1]; o[6] = (__bf16)v1[2]; o[7] = (__bf16)v1[3];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(s1_u32x4, o), yrsrc, yoff, 0, APSE_NT ? 2 : 0);
+                } else {
+                    f16x8 o;
+                    o[0] = (_Float16)v0[0]; o[1] = (_Float16)v0[1]; o[2] = (_Float16)v0[2]; o[3] = (_Float16)v0[3];
+                    o[4] = (_Float16)v1[0]; o[5] = (_Float16)v1[1]; o[6] = (_Float16)v1[2]; o[7] = (_Float16)v1[3];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(s1_u32x4, o), yrsrc, yoff, 0, APSE_NT ? 2 : 0);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -249,6 +251,7 @@ bool apse_conv1x1_stream_ok(const ConvParams& p) {
     if (p.out_mode != 0 || p.y_coff != 0 || p.y_ld != p.Cout || p.splitk != 1 || p.m_count || p.tile_cnt) return false;
     if (p.res_mode != 0 && p.res_mode != 1 && p.res_mode != 2) return false;
     if ((((size_t)p.B * p.H * p.W) << p.cin_log2) * (p.prec ? 2 : 4) >= 0xfffffff0ull) return false;
+    if (((size_t)p.M + 128) * (size_t)p.Cout * (p.prec ? 2 : 4) >= 0x70000000ull) return false;       // output / residual rows are addressed with 32-bit byte offsets
     // residual and output live in the operand's storage type (f32 mode: f32; 16-bit modes with 16-bit storage: that type)
     if (p.y_st != p.prec || (p.res_mode != 0 && p.res_st != p.prec)) return false;
     // f32: K = 64; (round 3) K = 128 and K = 256 with 64-column chunks -- half the accumulators, so the A strip (64 / 128 registers)
