@@ -26,6 +26,7 @@ __device__ __forceinline__ f32x16 g16_mfma(g16_f16x8 a, g16_f16x8 b, f32x16 c) {
 #define GL_ABLATE 0      // diagnostics only (tools/gpu_glds_ablate.sh): 1 no MFMA, 2 DMAs of the first two stages only, 3 no fragment reads, 4 two of three A fetches out of range, 5 no output stores, 6 two stages only
 #endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned g16_u32x2 __attribute__((ext_vector_type(2)));
 
 // BM x BN = 256 x 128: 8 waves as 4 x 2, 64 x 64 per wave, three stages of 48 KB.  256 x 256: 8 waves as 2 x 4, 128 x 64 per wave,
 // two stages of 64 KB -- per matrix-pipe cycle a third fewer bytes through L2 -> LDS (32 instead of 47 B/clk/CU, of ~64 the port
@@ -220,6 +221,59 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
             const bool vec = ((p.y_ld & 3) == 0) && ((p.y_coff & 3) == 0) && (p.y_coff + n + 4 <= p.y_ld);
+            // Fast path (every trunk layer): output and residual stored in the operand type, whole 8-byte groups.  Rows go through
+            // buffer descriptors sized to M rows -- a row past M is out of range by construction (loads give zeros, stores are
+            // dropped) -- with ONE per-thread byte offset and a uniform step per pass: no branch, no 64-bit arithmetic, no run-time
+            // storage-type switch per element (the general form below costs ~2x the instructions of this one).
+            const bool fast = vec && p.y_st == PR && (p.res_mode == 0 || (p.res_mode == 1 && p.res_st == PR && p.res)) &&
+                              ((size_t)M + GL_BM) * (size_t)p.y_ld * 2 < 0xfffffff0ull && ((size_t)M + GL_BM) * (size_t)p.Cout * 2 < 0xfffffff0ull;
+            if (fast) {
+                const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((unsigned)M * (unsigned)p.y_ld * 2u), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res_mode ? p.res : p.y), 0,
+                                                                                       (int)(p.res_mode ? (unsigned)M * (unsigned)p.Cout * 2u : 0u), 0x00020000);
+                const unsigned ystep = (unsigned)(RPP * p.y_ld) * 2u, rstep = (unsigned)(RPP * p.Cout) * 2u;
+                const unsigned yo = (unsigned)((m0 + r0) * p.y_ld + p.y_coff + n) * 2u, ro = (unsigned)((m0 + r0) * p.Cout + n) * 2u;
+#pragma unroll
+                for (int g0 = 0; g0 < GL_BM / RPP; g0 += 8) {
+                    g16_u32x2 rg[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        rg[i] = p.res_mode ? __builtin_bit_cast(g16_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rrsrc, (int)(ro + (unsigned)(g0 + i) * rstep), 0, 0))
+                                           : g16_u32x2{0u, 0u};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int r = r0 + (g0 + i) * RPP;
+                        f32x4 val = *reinterpret_cast<const f32x4*>(Cs + r * LDC + c4 * 4);
+                        val += bias4;
+                        f32x4 rv;
+                        if constexpr (PR == 1) {
+                            rv = f32x4{__uint_as_float(rg[i][0] << 16), __uint_as_float(rg[i][0] & 0xffff0000u), __uint_as_float(rg[i][1] << 16),
+                                       __uint_as_float(rg[i][1] & 0xffff0000u)};
+                        } else {
+                            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                            const h4 hv = __builtin_bit_cast(h4, rg[i]);
+                            rv = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+                        }
+                        val += rv;
+                        if (p.relu) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) asm("v_max_f32 %0, 0, %1" : "=v"(val[k]) : "v"(val[k]));      // x > 0 ? x : 0 (-0, NaN -> +0)
+                        }
+                        g16_u32x2 o;
+                        if constexpr (PR == 1) {
+                            typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+                            b4 t; t[0] = (__bf16)val[0]; t[1] = (__bf16)val[1]; t[2] = (__bf16)val[2]; t[3] = (__bf16)val[3];
+                            o = __builtin_bit_cast(g16_u32x2, t);
+                        } else {
+                            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                            h4 t; t[0] = (_Float16)val[0]; t[1] = (_Float16)val[1]; t[2] = (_Float16)val[2]; t[3] = (_Float16)val[3];
+                            o = __builtin_bit_cast(g16_u32x2, t);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b64(o, yrsrc, (int)(yo + (unsigned)(g0 + i) * ystep), 0, APSE_NT ? 2 : 0);
+                    }
+                }
+                continue;
+            }
             auto res_load = [&](int m) -> f32x4 {
                 f32x4 rv = {0.f, 0.f, 0.f, 0.f};
                 if (m < M) {
