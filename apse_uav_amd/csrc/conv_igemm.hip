@@ -444,11 +444,42 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvPa
             }
             return rv;
         };
+        // Fast path of the direct epilogue (round 4; every trunk layer takes it): plain NHWC output, output and same-resolution
+        // residual in ONE storage type known at compile time (f32, or the operand type of the 16-bit kernels), whole vectors.  Rows
+        // go through buffer descriptors sized to M rows -- a row past M is out of range by construction: its loads give zeros, its
+        // stores are dropped -- with one byte offset per thread and a uniform step per pass: no branch, no 64-bit arithmetic and
+        // no run-time storage switch per element.  Same values in the same order as the general form.
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const bool want_res = direct && p.res_mode != 0;
+        const bool fast_ok = direct && p.out_mode == 0 && n < p.Cout && ((p.y_ld & 3) == 0) && ((p.y_coff & 3) == 0) && (p.y_coff + n + 4 <= p.y_ld) &&
+                             (p.res_mode == 0 || (p.res_mode == 1 && p.res_st == p.y_st)) && (p.y_st == 0 || p.y_st == PR) &&
+                             ((size_t)M + BM) * (size_t)p.y_ld * 4 < 0xfffffff0ull && ((size_t)M + BM) * (size_t)p.Cout * 4 < 0xfffffff0ull;
+        const unsigned fes = p.y_st ? 2u : 4u;
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((unsigned)M * (unsigned)p.y_ld * fes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(want_res ? p.res : p.y), 0,
+                                                                               (int)(want_res ? (unsigned)M * (unsigned)p.Cout * fes : 0u), 0x00020000);
+        const unsigned ystep = (unsigned)(RPP * p.y_ld) * fes, rstep = (unsigned)(RPP * p.Cout) * fes;
+        const unsigned yo = (unsigned)((m0 + r0) * p.y_ld + p.y_coff + n) * fes, ro = (unsigned)((m0 + r0) * p.Cout + n) * fes;
+        auto fast_rload = [&](int pass) -> f32x4 {
+            const int off = (int)(ro + (unsigned)pass * rstep);
+            if (PR == 0 || p.y_st == 0) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0));
+            const u32x2_t q = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rrsrc, off, 0, 0));
+            if constexpr (PR == 2) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 hv = __builtin_bit_cast(h4, q);
+                return f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            } else {
+                return f32x4{__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xffff0000u), __uint_as_float(q[1] << 16), __uint_as_float(q[1] & 0xffff0000u)};
+            }
+        };
         // the first group of residual rows is requested BEFORE the accumulators go through LDS: its HBM / MALL round
         // trip (the skip tensor was written two or three layers ago) overlaps the C-tile shuffle and the barrier
         f32x4 rgrp[RG];
-        const bool want_res = direct && p.res_mode != 0;
-        if (want_res) {
+        if (want_res && fast_ok) {
+#pragma unroll
+            for (int i = 0; i < RG; ++i) rgrp[i] = fast_rload(i);
+        } else if (want_res) {
 #pragma unroll
             for (int i = 0; i < RG; ++i) rgrp[i] = res_load(m0 + r0 + i * RPP);
         } else {
@@ -505,7 +536,40 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvPa
                 for (int k = 0; k < 4; ++k) if (n + k < p.Cout) apse_st1(p.y, dst + k, val[k], p.y_st);
             }
         };
-        if (direct) {
+        if (fast_ok) {
+#pragma unroll
+            for (int g0 = 0; g0 < PASSES; g0 += RG) {
+                if (g0 > 0 && want_res) {
+#pragma unroll
+                    for (int i = 0; i < RG; ++i) rgrp[i] = fast_rload(g0 + i);
+                }
+#pragma unroll
+                for (int i = 0; i < RG; ++i) {
+                    f32x4 val = ctile(r0 + (g0 + i) * RPP);
+                    val += bias4;
+                    val += rgrp[i];
+                    if (p.relu) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) asm("v_max_f32 %0, 0, %1" : "=v"(val[k]) : "v"(val[k]));      // x > 0 ? x : 0 (-0, NaN -> +0)
+                    }
+                    const int off = (int)(yo + (unsigned)(g0 + i) * ystep);
+                    if (PR == 0 || p.y_st == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, val), yrsrc, off, 0, APSE_NT ? 2 : 0);
+                    else {
+                        u32x2_t o;
+                        if constexpr (PR == 2) {
+                            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                            h4 t; t[0] = (_Float16)val[0]; t[1] = (_Float16)val[1]; t[2] = (_Float16)val[2]; t[3] = (_Float16)val[3];
+                            o = __builtin_bit_cast(u32x2_t, t);
+                        } else {
+                            typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+                            b4 t; t[0] = (__bf16)val[0]; t[1] = (__bf16)val[1]; t[2] = (__bf16)val[2]; t[3] = (__bf16)val[3];
+                            o = __builtin_bit_cast(u32x2_t, t);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b64(o, yrsrc, off, 0, APSE_NT ? 2 : 0);
+                    }
+                }
+            }
+        } else if (direct) {
             if (n < p.Cout) {
 #pragma unroll
                 for (int g0 = 0; g0 < PASSES; g0 += RG) {
