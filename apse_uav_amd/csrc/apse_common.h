@@ -100,6 +100,13 @@ __device__ __forceinline__ f32x4 apse_ld4(const void* base, size_t idx, int st) 
 #else
 #define APSE_NT_STORE(v, ptr) (*(ptr) = (v))
 #endif
+// ReLU as the select `x > 0 ? x : 0` computes it (-0 and NaN give +0) in ONE instruction: v_max_f32 with the constant first.  Written
+// in C the compiler emits a canonicalising `v_max x, x` in front of the max (IEEE mode), i.e. two instructions per element.
+__device__ __forceinline__ float apse_relu(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 __device__ __forceinline__ void apse_st4(void* base, size_t idx, f32x4 v, int st) {
     if (st == 0) { APSE_NT_STORE(v, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + idx)); return; }
     if (st == 1) {

@@ -86,6 +86,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w1), 0, 64 * K1 * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w2), 0, 64 * 576 * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w3), 0, 256 * 64 * 2, 0x00020000);
+    const unsigned map_bytes = (unsigned)(p.B * p.H * p.W) * 512u;      // residual and output maps: [B][H][W][256] 16-bit
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.res), 0, (int)map_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)map_bytes, 0x00020000);
     auto w_fetch = [&](auto QC) {
         constexpr int Q = decltype(QC)::value;
         if constexpr (Q == 0) {
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
             for (int v = 0; v < 16; ++v) {
                 const int rl = (v & 3) + 8 * (v >> 2) + 4 * fh;
                 float u0 = acc[0][v] + bi0, u1 = acc[1][v] + bi1, u2 = acc[2][v] + bi2;
-                u0 = u0 > 0.f ? u0 : 0.f; u1 = u1 > 0.f ? u1 : 0.f; u2 = u2 > 0.f ? u2 : 0.f;
+                u0 = apse_relu(u0); u1 = apse_relu(u1); u2 = apse_relu(u2);
                 if (!((vm0 >> rl) & 1u)) { u0 = 0.f; u1 = 0.f; }
                 if (!((vm1 >> rl) & 1u)) u2 = 0.f;
                 const int r0 = wave * 32 + rl, r1 = rt1 * 32 + rl;
@@ -212,19 +215,16 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
         // residual rows of the tile (16 pieces of 16 B per lane: rows erow + 8 i, 8 channels of each 64-column chunk): requested
         // here so that they arrive under phase 2 -- fetched chunk by chunk inside phase 3, each exposed a full L2 round trip
         f32x4 rr[4][4];
-        unsigned pix[4];                          // element offsets: B * H * W * 256 < 2^32 (checked by the launcher)
-        bool live[4];
+        unsigned pixb[4];                         // BYTE offsets into res / y: B * H * W * 512 < 0x70000000 (checked by the launcher); a pixel
+                                                  // outside the map gets an offset past the descriptors' range (loads give zeros, stores are dropped)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int q = wave * 32 + erow + 8 * i;
             const int oy = oy0 + (q >> 4), ox = ox0 + (q & 15);
-            live[i] = oy < p.H && ox < p.W;
-            pix[i] = (unsigned)((b * p.H + oy) * p.W + ox) * 256u + (unsigned)ecol;
+            pixb[i] = (oy < p.H && ox < p.W) ? ((unsigned)((b * p.H + oy) * p.W + ox) * 256u + (unsigned)ecol) * 2u : 0x80000000u;
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {
-                rr[ch][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (live[i]) rr[ch][i] = *reinterpret_cast<const f32x4*>(p.res + pix[i] + ch * 64);          // 8 x 16 bit
-            }
+            for (int ch = 0; ch < 4; ++ch)
+                rr[ch][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)(pixb[i] + ch * 128u), 0, 0));       // 8 x 16 bit
         }
 
         // ================================================================== phase 2: conv2 3x3 from the t1 tile
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
             for (int v = 0; v < 16; ++v) {
                 const int r = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * fh;
                 float u0 = acc[0][v] + bi0, u1 = acc[1][v] + bi1;
-                u0 = u0 > 0.f ? u0 : 0.f; u1 = u1 > 0.f ? u1 : 0.f;
+                u0 = apse_relu(u0); u1 = apse_relu(u1);
                 *reinterpret_cast<uint16_t*>(t2 + bn_slot(r, fr >> 3) + (fr & 7) * 2) = bn_round<PR>(u0);
                 *reinterpret_cast<uint16_t*>(t2 + bn_slot(r, 4 + (fr >> 3)) + (fr & 7) * 2) = bn_round<PR>(u1);
             }
@@ -276,17 +276,14 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
             constexpr int ch = decltype(CC)::value;               // 64-column chunk of the 256 output channels
             const int nb = ch * 64 + ecol;
             f32x16 ac3[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) ac3[j][v] = 0.f;
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // C operand of the first MFMAs
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int ls = 2 * c + fh;
                 const f32x4 bf0 = *reinterpret_cast<const f32x4*>(Ws + bn_slot(ch * 64 + fr, ls));
                 const f32x4 bf1 = *reinterpret_cast<const f32x4*>(Ws + bn_slot(ch * 64 + 32 + fr, ls));
-                ac3[0] = bn_mfma(__builtin_bit_cast(op8, a3[c]), __builtin_bit_cast(op8, bf0), ac3[0]);
-                ac3[1] = bn_mfma(__builtin_bit_cast(op8, a3[c]), __builtin_bit_cast(op8, bf1), ac3[1]);
+                ac3[0] = bn_mfma(__builtin_bit_cast(op8, a3[c]), __builtin_bit_cast(op8, bf0), c == 0 ? zero16 : ac3[0]);
+                ac3[1] = bn_mfma(__builtin_bit_cast(op8, a3[c]), __builtin_bit_cast(op8, bf1), c == 0 ? zero16 : ac3[1]);
             }
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
@@ -313,20 +310,21 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
                 }
                 v0 += x0; v1 += x1;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { v0[k] = v0[k] > 0.f ? v0[k] : 0.f; v1[k] = v1[k] > 0.f ? v1[k] : 0.f; }
-                if (live[i]) {
-                    if constexpr (PR == 1) {
-                        bf16x8 o;
-                        o[0] = (__bf16)v0[0]; o[1] = (__bf16)v0[1]; o[2] = (__bf16)v0[2]; o[3] = (__bf16)v0[3];
-                        o[4] = (__bf16)v1[0]; o[5] = (__bf16)v1[1]; o[6] = (__bf16)v1[2]; o[7] = (__bf16)v1[3];
-                        APSE_NT_STORE(o, reinterpret_cast<bf16x8*>(p.y + pix[i] + ch * 64));
-                    } else {
-                        bn_f16x8 o;
-                        o[0] = (_Float16)v0[0]; o[1] = (_Float16)v0[1]; o[2] = (_Float16)v0[2]; o[3] = (_Float16)v0[3];
-                        o[4] = (_Float16)v1[0]; o[5] = (_Float16)v1[1]; o[6] = (_Float16)v1[2]; o[7] = (_Float16)v1[3];
-                        APSE_NT_STORE(o, reinterpret_cast<bn_f16x8*>(p.y + pix[i] + ch * 64));
-                    }
+                for (int k = 0; k < 4; ++k) { v0[k] = apse_relu(v0[k]); v1[k] = apse_relu(v1[k]); }
+                typedef unsigned bn_u32x4 __attribute__((ext_vector_type(4)));
+                bn_u32x4 ob;
+                if constexpr (PR == 1) {
+                    bf16x8 o;
+                    o[0] = (__bf16)v0[0]; o[1] = (__bf16)v0[1]; o[2] = (__bf16)v0[2]; o[3] = (__bf16)v0[3];
+                    o[4] = (__bf16)v1[0]; o[5] = (__bf16)v1[1]; o[6] = (__bf16)v1[2]; o[7] = (__bf16)v1[3];
+                    ob = __builtin_bit_cast(bn_u32x4, o);
+                } else {
+                    bn_f16x8 o;
+                    o[0] = (_Float16)v0[0]; o[1] = (_Float16)v0[1]; o[2] = (_Float16)v0[2]; o[3] = (_Float16)v0[3];
+                    o[4] = (_Float16)v1[0]; o[5] = (_Float16)v1[1]; o[6] = (_Float16)v1[2]; o[7] = (_Float16)v1[3];
+                    ob = __builtin_bit_cast(bn_u32x4, o);
                 }
+                __builtin_amdgcn_raw_buffer_store_b128(ob, yrsrc, (int)(pixb[i] + ch * 128u), 0, APSE_NT ? 2 : 0);
             }
             __builtin_amdgcn_wave_barrier();
         };
@@ -338,12 +336,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
 }
 
 // Eligible: 16-bit storage (x, residual, y and the filters in the operand type), 64 mid channels, 256 output channels,
-// Cin = 64 or 256, stride 1, maps below 4 GiB.  Returns APSE_E_INVALID otherwise (the caller keeps the three-kernel form).
+// Cin = 64 or 256, stride 1, input below 4 GiB, residual / output maps below 1.75 GiB.  Returns APSE_E_INVALID otherwise (the caller keeps the three-kernel form).
 extern "C" int apse_k_bottleneck64_fused16(const void* x, const void* res, void* y, const uint16_t* w1, const float* b1,
                                            const uint16_t* w2, const float* b2, const uint16_t* w3, const float* b3, int B, int H,
                                            int W, int K1, int prec, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if ((prec != 1 && prec != 2) || (K1 != 64 && K1 != 256) || B < 1 || H < 1 || W < 1) return APSE_E_INVALID;
-    if ((size_t)B * H * W * K1 * 2 >= 0xfffffff0ull || (size_t)B * H * W * 256 >= 0xfffffff0ull) return APSE_E_INVALID;
+    if ((size_t)B * H * W * K1 * 2 >= 0xfffffff0ull || (size_t)B * H * W * 512 >= 0x70000000ull) return APSE_E_INVALID;   // (byte offsets; 0x80000000 marks a dead row)
     BneckParams p;
     p.x = reinterpret_cast<const uint16_t*>(x); p.res = reinterpret_cast<const uint16_t*>(res); p.y = reinterpret_cast<uint16_t*>(y);
     p.w1 = w1; p.w2 = w2; p.w3 = w3; p.b1 = b1; p.b2 = b2; p.b3 = b3;

@@ -298,8 +298,7 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
                     val += bias4;
                     val += rg[i];
                     if (p.relu) {
-                        val[0] = val[0] > 0.f ? val[0] : 0.f; val[1] = val[1] > 0.f ? val[1] : 0.f;
-                        val[2] = val[2] > 0.f ? val[2] : 0.f; val[3] = val[3] > 0.f ? val[3] : 0.f;
+                        val[0] = apse_relu(val[0]); val[1] = apse_relu(val[1]); val[2] = apse_relu(val[2]); val[3] = apse_relu(val[3]);
                     }
                     const size_t dst = (size_t)m * p.y_ld + p.y_coff + n;
                     if (GL_ABLATE == 5) { if (val[0] == 12345.678f) apse_st4(p.y, dst, val, p.y_st); }      // 5: no output stores

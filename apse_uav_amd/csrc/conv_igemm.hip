@@ -527,8 +527,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvPa
                 dst = (((size_t)b * 2 * p.OH + 2 * oy + (g >> 1)) * (2 * p.OW) + 2 * ox + (g & 1)) * p.cdec + co;
             }
             if (p.relu) {
-                val[0] = val[0] > 0.f ? val[0] : 0.f; val[1] = val[1] > 0.f ? val[1] : 0.f;
-                val[2] = val[2] > 0.f ? val[2] : 0.f; val[3] = val[3] > 0.f ? val[3] : 0.f;
+                val[0] = apse_relu(val[0]); val[1] = apse_relu(val[1]); val[2] = apse_relu(val[2]); val[3] = apse_relu(val[3]);
             }
             if (vec_direct) {
                 apse_st4(p.y, dst, val, p.y_st);
@@ -677,7 +676,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvParams p) {
             const int dy = g >> 1, dx = g & 1;
             dst = (((size_t)b * 2 * p.OH + 2 * oy + dy) * (2 * p.OW) + 2 * ox + dx) * p.cdec + co;
         }
-        if (p.relu) val = val > 0.f ? val : 0.f;
+        if (p.relu) val = apse_relu(val);
         apse_st1(p.y, dst, val, p.y_st);
     }
 }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv_skinny16(const ConvParams p) {
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + 16 * t + 4 * ks + r;
                     float v = acc[t][r] + bi;
-                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    if (p.relu) v = apse_relu(v);
                     if (m < M) p.y[(size_t)m * p.y_ld + p.y_coff + col] = v;
                 }
         }

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, SP_OCC) void stem_s2d_pool16(const uint16_t* _
                 for (int v = 0; v < 16; ++v) {
                     const int m = (mh + 2 * (g0 + i)) * 32 + (v & 3) + 8 * (v >> 2) + 4 * fh;
                     float val = acc[i][v] + bia;
-                    val = val > 0.f ? val : 0.f;
+                    val = apse_relu(val);
                     uint16_t bits;
                     if constexpr (PR == 1) bits = __builtin_bit_cast(uint16_t, (__bf16)val);
                     else bits = __builtin_bit_cast(uint16_t, (_Float16)val);
