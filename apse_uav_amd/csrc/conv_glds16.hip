@@ -77,21 +77,34 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
 
     // ---- this lane's DMA rows: A groups 4 wave .. 4 wave + 3, B groups 2 wave, 2 wave + 1 (a group = 8 rows x 128 B = one
     // wave instruction); LDS slot (row, lane & 7) receives chunk cs = (lane & 7) ^ swz(row)
-    int a_iy0[APW], a_ix0[APW], a_base[APW], a_cs[APW];
+    // Per lane and A piece: ONE byte offset (the row's centre pixel + the lane's swizzled chunk) and a bit mask of the filter taps whose
+    // input pixel lies inside the map.  Everything that changes from stage to stage is wave-uniform -- the tap's displacement and the
+    // channel slice -- and rides in the instruction's scalar offset; a masked tap (zero padding) or a row past M turns the vector
+    // offset into 0xffffffff, which the descriptor's range check answers with zeros.  3 vector instructions per piece and stage
+    // (round 4; the earlier form recomputed pixel coordinates and two range tests per piece: ~9).  The descriptor's base is moved
+    // back by the displacement of tap (0, 0), so that every tap's scalar offset is >= 0; no access ever goes below p.x (such taps
+    // are masked).
+    unsigned a_voff[APW], a_taps[APW];
+    const unsigned xbytes = (((unsigned)(p.B * p.H * p.W)) << p.cin_log2) << 1;
+    const unsigned xback = (((unsigned)(p.pad * p.W + p.pad)) << p.cin_log2) << 1;
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
         const int row = (wave * APW + i) * 8 + (lane >> 3);
         const int m = m0 + row;
-        a_cs[i] = ((lane & 7) ^ ((row >> 1) & 7)) << 3;            // element offset of the chunk inside the 64-element step
+        const int cs = ((lane & 7) ^ ((row >> 1) & 7)) << 3;       // element offset of the chunk inside the 64-element step
+        a_voff[i] = 0u; a_taps[i] = 0u;
         if (m < M) {
             const int b = m / ohw, rem = m - b * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
-            a_iy0[i] = oy * p.stride - p.pad;
-            a_ix0[i] = ox * p.stride - p.pad;
-            a_base[i] = ((b * p.H + a_iy0[i]) * p.W + a_ix0[i]) << p.cin_log2;
-        } else {
-            a_iy0[i] = -(1 << 28);
-            a_ix0[i] = 0;
-            a_base[i] = 0;
+            const int cy = oy * p.stride, cx = ox * p.stride;                    // centre pixel: tap (pad, pad)
+            a_voff[i] = ((((unsigned)((b * p.H + cy) * p.W + cx)) << p.cin_log2) + (unsigned)cs) << 1;
+            unsigned tm = 0xffffffffu;
+            if (p.pad > 0) {
+                tm = 0u;
+                for (int ky = 0; ky < p.KH; ++ky)
+                    for (int kx = 0; kx < p.KW; ++kx)
+                        if ((unsigned)(cy - p.pad + ky) < (unsigned)p.H && (unsigned)(cx - p.pad + kx) < (unsigned)p.W) tm |= 1u << (ky * p.KW + kx);
+            }
+            a_taps[i] = tm;
         }
     }
     unsigned b_off[BPW];
@@ -101,33 +114,30 @@ __global__ __launch_bounds__(512) void conv_glds16(const ConvParams p) {
         const int cs = ((lane & 7) ^ ((row >> 1) & 7)) << 3;
         b_off[i] = (unsigned)((((size_t)(n0 + row) * w_row) + cs) << 1);       // bytes; filters are padded to Cout_p = 128 k rows
     }
-    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0,
-                                                                    (int)(((unsigned)(p.B * p.H * p.W) << p.cin_log2) << 1), 0x00020000);
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x) - xback), 0, (int)(xbytes + xback), 0x00020000);
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w16), 0,
                                                                     (int)((((unsigned)(tiles_n * GL_BN)) * (unsigned)w_row) << 1), 0x00020000);
     int ld_r = 0, ld_q = 0;
     // One DMA "piece" = one wave instruction (8 rows x 128 B).  Pieces 0..APW-1: this wave's A groups, APW..: its B groups.
     // piece 0 also computes the step's scalars and advances (filter row, step) -- pieces of a stage are issued in order.
-    int cur_q0 = 0, cur_rowoff = 0, cur_r = 0;
-    unsigned cur_woff = 0;
+    int cur_tap = 0;
+    unsigned cur_xoff = 0, cur_woff = 0;
     auto issue_piece = [&](int buf, int j) {
         if (j == 0) {
-            cur_q0 = ld_q << 6;                                      // element offset of this step inside the filter row's run
-            cur_r = ld_r;
-            cur_rowoff = ((ld_r * p.W) << p.cin_log2) + cur_q0;
-            cur_woff = (unsigned)((ld_r * p.KWCp + cur_q0) << 1);
+            const int q0 = ld_q << 6;                                // element offset of this step inside the filter row's run: kx * Cin + channel slice
+            const int kx = q0 >> p.cin_log2;
+            cur_tap = ld_r * p.KW + kx;
+            cur_xoff = (unsigned)((((ld_r * p.W + kx) << p.cin_log2) + (q0 & ((1 << p.cin_log2) - 1))) << 1);
+            cur_woff = (unsigned)((ld_r * p.KWCp + q0) << 1);
             if (++ld_q == steps_per_row) { ld_q = 0; ++ld_r; }
         }
         if (j < APW) {
-            const int iy = a_iy0[j] + cur_r;
-            const int px = a_ix0[j] + ((cur_q0 + a_cs[j]) >> p.cin_log2);
-            const unsigned okm = (unsigned)-(int)(((unsigned)iy < (unsigned)p.H) & ((unsigned)px < (unsigned)p.W));
-            unsigned off = (((unsigned)(a_base[j] + cur_rowoff + a_cs[j]) << 1) & okm) | (0xfffffff0u & ~okm);
-            if (GL_ABLATE == 4 && ((cur_q0 >> 6) % 3) != 0) off = 0xfffffff0u;      // what if two of three A fetches were free (tap reuse)?
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(smem + buf * GL_STAGE + wave * (APW * 1024) + j * 1024), 16, (int)off, 0, 0, 0);
+            unsigned off = a_voff[j] | (((a_taps[j] >> (cur_tap & 31)) & 1u) - 1u);                       // tap inside the map: the offset; else all ones
+            if (GL_ABLATE == 4 && (ld_q % 3) != 0) off = 0xffffffffu;      // what if two of three A fetches were free (tap reuse)?
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(smem + buf * GL_STAGE + wave * (APW * 1024) + j * 1024), 16, (int)off, (int)cur_xoff, 0, 0);
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(smem + buf * GL_STAGE + GL_BM * 128 + wave * (BPW * 1024) + (j - APW) * 1024), 16,
-                                                     (int)(b_off[j - APW] + cur_woff), 0, 0, 0);
+                                                     (int)b_off[j - APW], (int)cur_woff, 0, 0);
         }
     };
     auto issue = [&](int buf) {
@@ -319,9 +329,11 @@ bool apse_conv_glds16_ok(const ConvParams& p) {
     if (!p.w16 || p.x_st != p.prec || p.cin_log2 < 6 || (p.KWCp & 63) != 0) return false;
     if (p.splitk != 1 || p.out_mode != 0 || p.m_count || p.tile_cnt) return false;
     if ((p.Cout & 3) != 0) return false;
+    if (p.pad > 0 && p.KH * p.KW > 32) return false;                     // one validity bit per filter tap and lane
     const size_t xbytes = (((size_t)p.B * p.H * p.W) << p.cin_log2) * 2;
     const size_t wbytes = (size_t)((p.Cout + 127) / 128 * 128) * p.KH * p.KWCp * 2;
-    return xbytes < 0xfffffff0ull && wbytes < 0xfffffff0ull;
+    const size_t xback = (((size_t)p.pad * p.W + p.pad) << p.cin_log2) * 2;      // the activation descriptor starts this far in front of p.x
+    return xbytes + xback < 0xfffffff0ull && wbytes < 0xfffffff0ull;
 }
 
 template <int PR, int BM, int BN>
