@@ -636,6 +636,30 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_f32(const ConvPa
 }
 
 // Split-K second pass: fixed-order sum of the partial slabs (bitwise reproducible) + epilogue.
+// The same, four columns per thread: plain NHWC output, no or same-resolution residual, Cout / y_ld / y_coff multiples of 4 (every
+// split-K layer of the network).  Every element is the same sum in the same order (z ascending, + bias, + residual, ReLU) as in the
+// scalar kernel below, which stays for the deconvolution scatter and the upsampled residual.
+__global__ __launch_bounds__(256) void conv_splitk_reduce4(const ConvParams p) {
+    int M = p.M;
+    if (p.m_count) {
+        int lim = (*p.m_count) * p.m_per_item;
+        M = lim < M ? lim : M;
+    }
+    const unsigned c4 = (unsigned)p.Cout >> 2;
+    const unsigned total = (unsigned)M * c4;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        const unsigned m = e / c4, n = (e - m * c4) << 2;
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.ws + (size_t)m * p.Cout + n);
+        const size_t slab4 = ((size_t)p.M * p.Cout) >> 2;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < p.splitk; ++z) val += src[z * slab4];
+        if (p.bias) val += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.res_mode == 1) val += apse_ld4(p.res, (size_t)m * p.Cout + n, p.res_st);
+        if (p.relu) { val[0] = apse_relu(val[0]); val[1] = apse_relu(val[1]); val[2] = apse_relu(val[2]); val[3] = apse_relu(val[3]); }
+        apse_st4(p.y, (size_t)m * p.y_ld + p.y_coff + n, val, p.y_st);
+    }
+}
+
 __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvParams p) {
     int M = p.M;
     if (p.m_count) {
@@ -710,9 +734,11 @@ static int launch_cfg_x(const ConvParams& p, hipStream_t s, hipEvent_t ev0, hipE
     if (ev1) hipEventRecord(ev1, s);
     if (p.splitk > 1 && !p.tile_cnt) {
         const size_t total = (size_t)p.M * p.Cout;
-        int blocks = (int)((total + 255) / 256);
+        const bool vec4 = p.out_mode == 0 && (p.res_mode == 0 || p.res_mode == 1) && ((p.Cout | p.y_ld | p.y_coff) & 3) == 0 && total < 0x7fffffffull;
+        int blocks = (int)(((vec4 ? total / 4 : total) + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(conv_splitk_reduce, dim3(blocks), dim3(256), 0, s, p);
+        if (vec4) hipLaunchKernelGGL(conv_splitk_reduce4, dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(conv_splitk_reduce, dim3(blocks), dim3(256), 0, s, p);
     }
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
