@@ -100,7 +100,8 @@ __device__ __forceinline__ f32x4 ra_bin_direct(const void* fmap, int st, size_t 
 #ifndef RA_MINBLK
 #define RA_MINBLK 1        // second argument of __launch_bounds__: minimum 256-thread blocks per CU the register budget must allow
 #endif
-template <bool ST16>
+// ST: storage type of the maps at compile time (0 f32, 1 bf16, 2 f16)
+template <int ST>
 __global__ __launch_bounds__(256, RA_MINBLK) void roi_align_nhwc(const FpnMaps F, const float* __restrict__ rois,
                                                       const int* __restrict__ roi_img, const int* __restrict__ cnt,
                                                       const int* __restrict__ total, int per_img, int n_max, int R,
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256, RA_MINBLK) void roi_align_nhwc(const FpnMaps F
     const int ybase = btab[0][ph][0], ny = btab[0][ph][1], xbase = btab[1][pw][0], nx = btab[1][pw][1];
     const float* wyv = wtab[0][ph];
     const float* wxv = wtab[1][pw];
-    if constexpr (!ST16) {
+    if constexpr (ST == 0) {
         // f32 maps: one cell = 64 lanes x 16 B
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int T = ny * nx;
@@ -190,14 +191,47 @@ __global__ __launch_bounds__(256, RA_MINBLK) void roi_align_nhwc(const FpnMaps F
         }
         apse_st4(out, o, acc / cntf, out_st);
     } else {
-        // 16-bit maps: half-wave h takes the cells with (X & 1) == h, 32 lanes x 16 B each
+        // 16-bit maps: half-wave h takes the cells with (X & 1) == h, 32 lanes x 16 B each.  The cell stream (row-major over the window,
+        // RA_FLIGHT loads in flight) is addressed with ONE per-lane byte offset -- the lane's chunk of window cell (0, half) -- plus a
+        // wave-uniform scalar offset that walks the cells; the descriptor ends with this image's map, so whatever lies past it reads
+        // as zeros, and the padding iterations of the last group get an offset past the range.  The x weight of a cell past the
+        // window's last column is 0 in the tap table (no sample touches it), so such a lane adds +0 as before.  (Round 4: the loop
+        // was bound by the scalar unit -- 64-bit cell indices with selects, ~31 scalar + 23 vector instructions per cell.)
         const int half = lane >> 5, cg = lane & 31;
         const int np = (nx + 1) >> 1;                       // cell pairs per window row
         const int T = ny * np;
-        const size_t f0 = fimg + ((size_t)ybase * W + xbase) * 256 + cg * 8;
+        const size_t cell0 = fimg + ((size_t)ybase * W + xbase) * 256;                 // element index of window cell (0, 0)
+        const size_t img_end = (fimg + (size_t)H * W * 256) * 2;                       // bytes up to the end of this image's map
         f32x8 acc;
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        if (img_end < 0x7ffffff0ull) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(fmap), 0, (int)img_end, 0x00020000);
+            const unsigned voff = (unsigned)((cell0 + (size_t)half * 256 + cg * 8) * 2);
+            const unsigned rowb = (unsigned)W * 512u;
+            const float* wxh = wxv + half;                   // this half-wave's x weights: wxh[2 p]
+            int yy = 0, xp = 0;
+            unsigned soff = 0;
+            for (int t0 = 0; t0 < T; t0 += RA_FLIGHT) {
+                uint4 raw[RA_FLIGHT];
+                float w[RA_FLIGHT];
+#pragma unroll
+                for (int u = 0; u < RA_FLIGHT; ++u) {
+                    const bool live = yy < ny;
+                    w[u] = wyv[live ? yy : 0] * wxh[2 * xp];
+                    raw[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(live ? voff : 0x80000000u), (int)soff, 0));
+                    soff += 1024u;
+                    if (++xp == np) { xp = 0; ++yy; soff = (unsigned)yy * rowb; }
+                }
+#pragma unroll
+                for (int u = 0; u < RA_FLIGHT; ++u) {
+                    const f32x8 v = apse_cvt8(raw[u], ST);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += w[u] * v[k];
+                }
+            }
+        } else {
+        const size_t f0 = cell0 + cg * 8;
         int yy = 0, xp = 0;
         for (int t0 = 0; t0 < T; t0 += RA_FLIGHT) {
             uint4 raw[RA_FLIGHT];                            // RA_FLIGHT cell loads in flight per lane, converted when consumed
@@ -213,10 +247,11 @@ __global__ __launch_bounds__(256, RA_MINBLK) void roi_align_nhwc(const FpnMaps F
             }
 #pragma unroll
             for (int u = 0; u < RA_FLIGHT; ++u) {
-                const f32x8 v = apse_cvt8(raw[u], F.st);
+                const f32x8 v = apse_cvt8(raw[u], ST);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] += w[u] * v[k];
             }
+        }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = (acc[k] + __shfl_xor(acc[k], 32)) / cntf;
@@ -482,8 +517,9 @@ int apse_k_roi_align(const FpnMaps* F, const float* rois, const int* roi_img, co
     int parts = RA_TARGET_BLOCKS / blocks;
     const int max_parts = (R * R + 3) / 4;
     parts = parts < 1 ? 1 : (parts > max_parts ? max_parts : parts);
-    if (F->st) hipLaunchKernelGGL(roi_align_nhwc<true>, dim3(blocks, parts), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R, out, out_st);
-    else hipLaunchKernelGGL(roi_align_nhwc<false>, dim3(blocks, parts), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R, out, out_st);
+    if (F->st == 1) hipLaunchKernelGGL(roi_align_nhwc<1>, dim3(blocks, parts), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R, out, out_st);
+    else if (F->st == 2) hipLaunchKernelGGL(roi_align_nhwc<2>, dim3(blocks, parts), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R, out, out_st);
+    else hipLaunchKernelGGL(roi_align_nhwc<0>, dim3(blocks, parts), dim3(256), 0, s, *F, rois, roi_img, cnt, total, per_img, n_max, R, out, out_st);
     return hipGetLastError() == hipSuccess ? APSE_OK : APSE_E_HIP;
 }
 int apse_k_roi_pool(const void* feat, int st, int H, int W, const float* rois, const int* roi_img, const int* total, int n_max,
