@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr0 = lane & 31, fh0 = lane >> 5;
     const int srow = tid >> 3, slot = tid & 7;
+    // per-lane bases of the t1 / t2 element stores (see the phase-1 epilogue): [(v >> 1) & 1]
+    int eo[2];
+    eo[0] = (((fr0 >> 3) ^ (fh0 << 1)) << 4) + (fr0 & 7) * 2 + fh0 * 512;
+    eo[1] = (((fr0 >> 3) ^ (1 | (fh0 << 1))) << 4) + (fr0 & 7) * 2 + fh0 * 512;
     const int tiles_img = p.tiles_y * p.tiles_x;
     const int tiles = p.B * tiles_img;
     const int my_tiles = ((int)blockIdx.x < tiles) ? (tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
@@ -197,6 +201,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
             // bias, ReLU, zero outside the map, one rounding -> t1
             const float bi0 = p.b1[fr], bi1 = p.b1[32 + fr];
             const float bi2 = nt1 ? bi1 : bi0;
+            // element (row R0 + rl, column L * 8 + fr) of the swizzled tile, rl = (v & 3) + 8 (v >> 2) + 4 fh: with R0 a multiple of 32 the
+            // swizzle term (row >> 1) & 7 has the bits ((v >> 1) & 1, fh, (v >> 2) & 1), so the byte address is one of two per-lane bases
+            // (eo[(v >> 1) & 1], set up once per block) plus a compile-time immediate -- no address arithmetic per element.
+            char* const w3 = t1 + rt1 * 4096;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int rl = (v & 3) + 8 * (v >> 2) + 4 * fh;
@@ -204,10 +212,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
                 u0 = apse_relu(u0); u1 = apse_relu(u1); u2 = apse_relu(u2);
                 if (!((vm0 >> rl) & 1u)) { u0 = 0.f; u1 = 0.f; }
                 if (!((vm1 >> rl) & 1u)) u2 = 0.f;
-                const int r0 = wave * 32 + rl, r1 = rt1 * 32 + rl;
-                *reinterpret_cast<uint16_t*>(t1 + bn_slot(r0, fr >> 3) + (fr & 7) * 2) = bn_round<PR>(u0);
-                *reinterpret_cast<uint16_t*>(t1 + bn_slot(r0, 4 + (fr >> 3)) + (fr & 7) * 2) = bn_round<PR>(u1);
-                *reinterpret_cast<uint16_t*>(t1 + bn_slot(r1, 4 * nt1 + (fr >> 3)) + (fr & 7) * 2) = bn_round<PR>(u2);
+                const int imm = (v & 3) * 128 + (v >> 2) * 1024, gp = (v >> 2) & 1, eb = eo[(v >> 1) & 1];
+                *reinterpret_cast<uint16_t*>(t1 + wave * 4096 + eb + imm + (gp << 6)) = bn_round<PR>(u0);
+                *reinterpret_cast<uint16_t*>(t1 + wave * 4096 + eb + imm + ((gp ^ 1) << 6)) = bn_round<PR>(u1);
+                *reinterpret_cast<uint16_t*>(w3 + eb + imm + ((gp ^ nt1) << 6)) = bn_round<PR>(u2);
             }
         }
         // (the first barrier of the next stage is also "the halo tile of conv1 outputs is complete")
@@ -257,11 +265,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_fused16(const BneckParams
             const float bi0 = p.b2[fr], bi1 = p.b2[32 + fr];
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int r = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * fh;
                 float u0 = acc[0][v] + bi0, u1 = acc[1][v] + bi1;
                 u0 = apse_relu(u0); u1 = apse_relu(u1);
-                *reinterpret_cast<uint16_t*>(t2 + bn_slot(r, fr >> 3) + (fr & 7) * 2) = bn_round<PR>(u0);
-                *reinterpret_cast<uint16_t*>(t2 + bn_slot(r, 4 + (fr >> 3)) + (fr & 7) * 2) = bn_round<PR>(u1);
+                const int imm = (v & 3) * 128 + (v >> 2) * 1024, gp = (v >> 2) & 1, eb = eo[(v >> 1) & 1];
+                *reinterpret_cast<uint16_t*>(t2 + wave * 4096 + eb + imm + (gp << 6)) = bn_round<PR>(u0);
+                *reinterpret_cast<uint16_t*>(t2 + wave * 4096 + eb + imm + ((gp ^ 1) << 6)) = bn_round<PR>(u1);
             }
         }
         __builtin_amdgcn_wave_barrier();
